@@ -1,0 +1,348 @@
+// K1 -- CSR gather / segment reduce, and the fused per-layer SAGE aggregation built on it.
+//
+// Work decomposition: one ROW GROUP of GS lanes per destination row (GS = 8/16/32/64, chosen from the
+// row width so that each lane owns one float4 of the row; several rows share a wavefront when rows are
+// narrower than 256 floats).  A group walks its CSR segment four neighbours at a time: the neighbour
+// ids are read with one group-uniform load each, the four source rows are fetched as independent
+// 16-byte-per-lane loads (GS*16 contiguous bytes per row: one fully coalesced request), then added in
+// edge order, so the sum has the same association as a sequential scatter_add over the edge list.
+// No atomics anywhere: the backward pass gathers over the transposed lists (CSC) instead of scattering.
+//
+// HBM/L2 traffic per row: deg * F * 4 bytes of source rows + 4*deg + 8 bytes of indices + F*4 out.
+#include "kernels.h"
+
+namespace hmp {
+
+// ----- row access helpers -----------------------------------------------------------------------
+// VEC = 4: 16-byte accesses (pointer and ld 16-byte aligned); VEC = 1: scalar fall-back for arbitrary ld.
+template <int VEC>
+struct Acc;
+template <>
+struct Acc<4> {
+  float4 v;
+  __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+  __device__ __forceinline__ void add_div(const Acc& o, float d) { v.x += o.v.x / d; v.y += o.v.y / d; v.z += o.v.z / d; v.w += o.v.w / d; }
+  __device__ __forceinline__ void div(float d) { v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
+  __device__ __forceinline__ float& at(int i) { return (&v.x)[i]; }
+};
+template <>
+struct Acc<1> {
+  float v;
+  __device__ __forceinline__ void zero() { v = 0.f; }
+  __device__ __forceinline__ void load(const float* p) { v = *p; }
+  __device__ __forceinline__ void store(float* p) const { *p = v; }
+  __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
+  __device__ __forceinline__ void add_div(const Acc& o, float d) { v += o.v / d; }
+  __device__ __forceinline__ void div(float d) { v /= d; }
+  __device__ __forceinline__ float& at(int) { return v; }
+};
+
+// sum_{k in [b,e)} x[col[k]][c .. c+VEC)   in edge order; NV column chunks per lane (stride GS*VEC)
+template <int GS, int NV, int VEC>
+__device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __restrict__ x, int ld, const int* __restrict__ col,
+                                           int b, int e, int c0, int F) {
+  int k = b;
+  for (; k + 4 <= e; k += 4) {
+    const int j0 = col[k], j1 = col[k + 1], j2 = col[k + 2], j3 = col[k + 3];
+    Acc<VEC> v0[NV], v1[NV], v2[NV], v3[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = c0 + q * GS * VEC;
+      if (c < F) {
+        v0[q].load(x + (int64_t)j0 * ld + c);
+        v1[q].load(x + (int64_t)j1 * ld + c);
+        v2[q].load(x + (int64_t)j2 * ld + c);
+        v3[q].load(x + (int64_t)j3 * ld + c);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = c0 + q * GS * VEC;
+      if (c < F) { acc[q].add(v0[q]); acc[q].add(v1[q]); acc[q].add(v2[q]); acc[q].add(v3[q]); }
+    }
+  }
+  for (; k < e; ++k) {
+    const int j = col[k];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = c0 + q * GS * VEC;
+      if (c < F) { Acc<VEC> v; v.load(x + (int64_t)j * ld + c); acc[q].add(v); }
+    }
+  }
+}
+
+// sum_k g[tcol[k]][c..] / max(deg(tcol[k]),1)  (backward of the mean: every edge carries 1/deg(dst))
+template <int GS, int NV, int VEC>
+__device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* __restrict__ g, int ld, const int* __restrict__ tcol,
+                                             const int* __restrict__ rowptr, int mean, int b, int e, int c0, int F) {
+  for (int k = b; k < e; ++k) {
+    const int i = tcol[k];
+    float d = 1.f;
+    if (mean) {
+      const int deg = rowptr[i + 1] - rowptr[i];
+      d = (float)(deg > 1 ? deg : 1);
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = c0 + q * GS * VEC;
+      if (c < F) {
+        Acc<VEC> v;
+        v.load(g + (int64_t)i * ld + c);
+        if (mean) acc[q].add_div(v, d); else acc[q].add(v);
+      }
+    }
+  }
+}
+
+// ----- K1 unit kernels ----------------------------------------------------------------------------
+template <int GS, int NV, int VEC>
+__global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __restrict__ x, int ldx, int F, const int* __restrict__ rowptr,
+                                                               const int* __restrict__ col, int n_rows, float* __restrict__ out, int ldo) {
+  const int rpb = 256 / GS;
+  const int row = blockIdx.x * rpb + threadIdx.x / GS;
+  if (row >= n_rows) return;
+  const int c0 = (threadIdx.x % GS) * VEC;
+  Acc<VEC> acc[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) acc[q].zero();
+  const int b = rowptr[row], e = rowptr[row + 1];
+  gather_sum<GS, NV, VEC>(acc, x, ldx, col, b, e, c0, F);
+  const float d = (float)((e - b) > 1 ? (e - b) : 1);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = c0 + q * GS * VEC;
+    if (c < F) { acc[q].div(d); acc[q].store(out + (int64_t)row * ldo + c); }
+  }
+}
+
+template <int GS, int NV, int VEC>
+__global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __restrict__ g, int ldg, int F, const int* __restrict__ t_rowptr,
+                                                               const int* __restrict__ t_col, const int* __restrict__ rowptr, int n_rows,
+                                                               float* __restrict__ gx, int ldgx) {
+  const int rpb = 256 / GS;
+  const int row = blockIdx.x * rpb + threadIdx.x / GS;
+  if (row >= n_rows) return;
+  const int c0 = (threadIdx.x % GS) * VEC;
+  Acc<VEC> acc[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) acc[q].zero();
+  gather_sum_w<GS, NV, VEC>(acc, g, ldg, t_col, rowptr, 1, t_rowptr[row], t_rowptr[row + 1], c0, F);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = c0 + q * GS * VEC;
+    if (c < F) acc[q].store(gx + (int64_t)row * ldgx + c);
+  }
+}
+
+// ----- fused SAGE layer aggregation -----------------------------------------------------------------
+// out[t][i] = dropout(act( zroot[i] + bias + sum_e mean_{k in N_e(i)} z_e[col_k] ))
+template <int GS, int NV>
+__global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
+  constexpr int VEC = 4;
+  int ti = 0;
+  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
+  const AggDst& D = a.d[ti];
+  const int rpb = 256 / GS;
+  const int row = (blockIdx.x - D.block_start) * rpb + threadIdx.x / GS;
+  if (row >= D.n_rows) return;
+  const int c0 = (threadIdx.x % GS) * VEC;
+  Acc<VEC> tot[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = c0 + q * GS * VEC;
+    tot[q].zero();
+    if (c < D.F) {
+      if (D.zroot) tot[q].load(D.zroot + (int64_t)row * D.ldzr + D.roff + c);
+      if (D.bias) { Acc<VEC> b; b.load(D.bias + c); tot[q].add(b); }
+    }
+  }
+  for (int ii = 0; ii < D.n_in; ++ii) {
+    const AggIn& I = D.in[ii];
+    const int b = I.rowptr[row], e = I.rowptr[row + 1];
+    if (e == b) continue;
+    Acc<VEC> acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q].zero();
+    gather_sum<GS, NV, VEC>(acc, I.z + I.coff, I.ldz, I.col, b, e, c0, D.F);
+    const float d = a.mean ? (float)(e - b) : 1.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) tot[q].add_div(acc[q], d);
+  }
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c = c0 + q * GS * VEC;
+    if (c >= D.F) continue;
+    bool keep[4] = {true, true, true, true};
+    if (D.drop_on) drop_keep4(drop_resolve(D.drop), (uint32_t)row * (uint32_t)(D.ldo >> 2) + (uint32_t)(c >> 2), keep);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = tot[q].at(i);
+      if (D.act == HMP_ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (D.act == HMP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+      if (D.drop_on) v = keep[i] ? v * D.drop.scale : 0.f;
+      tot[q].at(i) = v;
+    }
+    tot[q].store(D.out + (int64_t)row * D.ldo + c);
+  }
+}
+
+// dz[s][j, seg_e] = sum_{k in out_e(j)} g'[dst_k] / deg(dst_k);   dz[s][j, root] = g'[s][j]
+template <int GS, int NV>
+__global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
+  constexpr int VEC = 4;
+  int si = 0;
+  while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
+  const TAggSrc& S = a.s[si];
+  const int rpb = 256 / GS;
+  const int row = (blockIdx.x - S.block_start) * rpb + threadIdx.x / GS;
+  if (row >= S.n_rows) return;
+  const int c0 = (threadIdx.x % GS) * VEC;
+  for (int oi = 0; oi < S.n_out; ++oi) {
+    const TAggOut& O = S.out[oi];
+    Acc<VEC> acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q].zero();
+    gather_sum_w<GS, NV, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, a.mean, O.t_rowptr[row], O.t_rowptr[row + 1], c0, O.F);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = c0 + q * GS * VEC;
+      if (c < O.F) acc[q].store(S.dz + (int64_t)row * S.lddz + O.coff + c);
+    }
+  }
+  if (S.groot) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c = c0 + q * GS * VEC;
+      if (c < S.Froot) {
+        Acc<VEC> v;
+        v.load(S.groot + (int64_t)row * S.ldgr + c);
+        v.store(S.dz + (int64_t)row * S.lddz + S.roff + c);
+      }
+    }
+  }
+}
+
+// ----- dispatch ---------------------------------------------------------------------------------------
+// lanes needed = ceil(F / VEC); GS = next pow2 in [8, 64]; NV = ceil(lanes / GS) <= 4
+static inline void pick_shape(int F, int vec, int& gs, int& nv) {
+  const int lanes = cdiv(F, vec);
+  gs = 8;
+  while (gs < 64 && gs < lanes) gs <<= 1;
+  nv = cdiv(lanes, gs);
+}
+
+#define HMP_DISPATCH_GS_NV(GSV, NVV, MACRO)                                       \
+  switch ((GSV) * 8 + (NVV)) {                                                    \
+    case 8 * 8 + 1: MACRO(8, 1); break;                                           \
+    case 16 * 8 + 1: MACRO(16, 1); break;                                         \
+    case 32 * 8 + 1: MACRO(32, 1); break;                                         \
+    case 64 * 8 + 1: MACRO(64, 1); break;                                         \
+    case 64 * 8 + 2: MACRO(64, 2); break;                                         \
+    case 64 * 8 + 3: MACRO(64, 3); break;                                         \
+    case 64 * 8 + 4: MACRO(64, 4); break;                                         \
+    default: HMP_FAIL(HMP_E_ARG, "row width %d not supported by the aggregation kernels (max %d)", Fmax, 64 * 4 * vec); \
+  }
+
+int agg_fwd_launch(AggArgs& a, hipStream_t st) {
+  int Fmax = 0, blocks = 0;
+  const int vec = 4;
+  for (int i = 0; i < a.n; ++i) Fmax = a.d[i].F > Fmax ? a.d[i].F : Fmax;
+  if (a.n == 0 || Fmax == 0) return HMP_OK;
+  int gs, nv;
+  pick_shape(Fmax, vec, gs, nv);
+  for (int i = 0; i < a.n; ++i) {
+    AggDst& D = a.d[i];
+    HMP_CHECK_ARG((D.ldo & 3) == 0 && (D.F & 3) == 0, "agg_fwd: widths must be padded to 4");
+    D.block_start = blocks;
+    blocks += cdiv(D.n_rows, 256 / gs);
+  }
+  a.total_blocks = blocks;
+  if (blocks == 0) return HMP_OK;
+#define LAUNCH_FWD(GS_, NV_) hipLaunchKernelGGL((agg_fwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
+  HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_FWD)
+#undef LAUNCH_FWD
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
+  int Fmax = 0, blocks = 0;
+  const int vec = 4;
+  for (int i = 0; i < a.n; ++i) {
+    for (int o = 0; o < a.s[i].n_out; ++o) Fmax = a.s[i].out[o].F > Fmax ? a.s[i].out[o].F : Fmax;
+    if (a.s[i].groot) Fmax = a.s[i].Froot > Fmax ? a.s[i].Froot : Fmax;
+  }
+  if (a.n == 0 || Fmax == 0) return HMP_OK;
+  int gs, nv;
+  pick_shape(Fmax, vec, gs, nv);
+  for (int i = 0; i < a.n; ++i) {
+    a.s[i].block_start = blocks;
+    blocks += cdiv(a.s[i].n_rows, 256 / gs);
+  }
+  a.total_blocks = blocks;
+  if (blocks == 0) return HMP_OK;
+#define LAUNCH_BWD(GS_, NV_) hipLaunchKernelGGL((agg_bwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
+  HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_BWD)
+#undef LAUNCH_BWD
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+template <bool FWD>
+static int segment_mean_dispatch(const float* in, int ldi, int F, const hmp_plan& plan, float* out, int ldo, hipStream_t st) {
+  const bool vec_ok = ((ldi & 3) == 0) && ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((F & 3) == 0);
+  const int vec = vec_ok ? 4 : 1;
+  const int Fmax = F;
+  const int n_rows = FWD ? plan.n_dst : plan.n_src;
+  if (n_rows == 0 || F == 0) return HMP_OK;
+  int gs, nv;
+  pick_shape(F, vec, gs, nv);
+  const int blocks = cdiv(n_rows, 256 / gs);
+#define LAUNCH_SM(GS_, NV_)                                                                                                   \
+  do {                                                                                                                        \
+    if (FWD) {                                                                                                                \
+      if (vec_ok) hipLaunchKernelGGL((segment_mean_fwd_kernel<GS_, NV_, 4>), dim3(blocks), dim3(256), 0, st, in, ldi, F, plan.d_rowptr, plan.d_col, n_rows, out, ldo); \
+      else hipLaunchKernelGGL((segment_mean_fwd_kernel<GS_, NV_, 1>), dim3(blocks), dim3(256), 0, st, in, ldi, F, plan.d_rowptr, plan.d_col, n_rows, out, ldo); \
+    } else {                                                                                                                  \
+      if (vec_ok) hipLaunchKernelGGL((segment_mean_bwd_kernel<GS_, NV_, 4>), dim3(blocks), dim3(256), 0, st, in, ldi, F, plan.d_t_rowptr, plan.d_t_col, plan.d_rowptr, n_rows, out, ldo); \
+      else hipLaunchKernelGGL((segment_mean_bwd_kernel<GS_, NV_, 1>), dim3(blocks), dim3(256), 0, st, in, ldi, F, plan.d_t_rowptr, plan.d_t_col, plan.d_rowptr, n_rows, out, ldo); \
+    }                                                                                                                         \
+  } while (0)
+  HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_SM)
+#undef LAUNCH_SM
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+}  // namespace hmp
+
+extern "C" int hmp_segment_mean_fwd(const float* d_x, int32_t ldx, int32_t F, hmp_plan plan, float* d_out, int32_t ldo, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(d_x && d_out && plan.d_rowptr, "hmp_segment_mean_fwd: null pointer");
+  HMP_CHECK_ARG(F >= 0 && ldx >= F && ldo >= F, "hmp_segment_mean_fwd: bad widths");
+  HMP_CHECK_ARG(plan.n_edges == 0 || plan.d_col, "hmp_segment_mean_fwd: null col");
+  // widths beyond one pass are processed in column panels
+  const int panel = ((ldx & 3) == 0 && (ldo & 3) == 0 && (F & 3) == 0) ? 1024 : 256;
+  for (int c = 0; c < F; c += panel) {
+    const int w = (F - c) < panel ? (F - c) : panel;
+    HMP_TRY((segment_mean_dispatch<true>(d_x + c, ldx, w, plan, d_out + c, ldo, (hipStream_t)stream)));
+  }
+  return HMP_OK;
+}
+
+extern "C" int hmp_segment_mean_bwd(const float* d_gout, int32_t ldg, int32_t F, hmp_plan plan, float* d_gx, int32_t ldgx, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(d_gout && d_gx && plan.d_rowptr && plan.d_t_rowptr, "hmp_segment_mean_bwd: null pointer");
+  HMP_CHECK_ARG(F >= 0 && ldg >= F && ldgx >= F, "hmp_segment_mean_bwd: bad widths");
+  HMP_CHECK_ARG(plan.n_edges == 0 || plan.d_t_col, "hmp_segment_mean_bwd: null t_col");
+  const int panel = ((ldg & 3) == 0 && (ldgx & 3) == 0 && (F & 3) == 0) ? 1024 : 256;
+  for (int c = 0; c < F; c += panel) {
+    const int w = (F - c) < panel ? (F - c) : panel;
+    HMP_TRY((segment_mean_dispatch<false>(d_gout + c, ldg, w, plan, d_gx + c, ldgx, (hipStream_t)stream)));
+  }
+  return HMP_OK;
+}

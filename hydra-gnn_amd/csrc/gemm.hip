@@ -1,0 +1,277 @@
+// K2 -- grouped fp32 GEMM on the gfx950 matrix cores.
+//
+// v_mfma_f32_32x32x2_f32 is a k-ordered fp32 FMA chain (no TF32-style truncation exists on CDNA4), so the
+// projection stays inside the 1e-5 parity budget of the reference's F.linear.  Scene-graph batches give
+// tall-skinny problems (M = nodes: 10^2..10^6, N,K = feature widths: 6..512), and several of them per
+// layer (one per node type), so the kernel is GROUPED: one launch walks a table of problems.
+//
+// Block = 4 wavefronts.  Tile shapes (BM x BN): 64x64 (2x2 waves), or 32x32 with the 4 waves splitting
+// the K range of each staged tile (small problems: 4x the workgroups, each 4x shorter; partial
+// accumulators are summed through LDS in a fixed order, so results are run-to-run identical).
+// Operands are staged global -> registers -> LDS in [k][m] / [k][n] order, which makes every MFMA
+// operand fetch a conflict-free ds_read_b32 (lanes 0-31 read 32 consecutive floats of one k row, lanes
+// 32-63 the next k row); the next tile's global loads are issued before the current tile's MFMAs.
+//
+// Forms: NT (x * W^T, nn.Linear), NN (dZ * W, input gradient, optional activation-derivative epilogue),
+// TN with split-K over node chunks (dZ^T * [x | 1], weight + bias gradient; slabs are reduced later).
+#include "kernels.h"
+
+namespace hmp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+// Loads a (ROWS x BK) tile into registers; logical element (r, k).
+//  kcontig = 1: memory is [r][k] (k contiguous)  -> per thread NV float4 along k
+//  kcontig = 0: memory is [k][r] (r contiguous)  -> per thread NV float4 along r
+template <int ROWS>
+struct TileRegs {
+  static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+  float4 v[NV];
+};
+
+template <int ROWS>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
+                                          int R, int n_real, int aug, int k0, int kend, bool vec_ok) {
+  constexpr int NV = TileRegs<ROWS>::NV;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * 256;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kcontig) {
+      const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
+      const int gr = r0 + r, gk = k0 + k4;
+      if (gr < R) {
+        const float* src = p + (int64_t)gr * ld + gk;
+        if (vec_ok && gk + 3 < kend) {
+          val = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (gk + 0 < kend) val.x = src[0];
+          if (gk + 1 < kend) val.y = src[1];
+          if (gk + 2 < kend) val.z = src[2];
+          if (gk + 3 < kend) val.w = src[3];
+        }
+      }
+    } else {
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      const int gk = k0 + k, gr = r0 + r4;
+      if (gk < kend) {
+        const float* src = p + (int64_t)gk * ld + gr;
+        if (vec_ok && gr + 3 < n_real) {
+          val = *reinterpret_cast<const float4*>(src);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = gr + j;
+            e[j] = (c < n_real) ? src[j] : ((aug && c == n_real) ? 1.0f : 0.0f);
+          }
+          val = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+    }
+    t.v[i] = val;
+  }
+}
+
+// LDS image is [k][LD] with LD = ROWS + 4
+template <int ROWS>
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS>& t, float* __restrict__ s, int kcontig) {
+  constexpr int NV = TileRegs<ROWS>::NV;
+  constexpr int LD = ROWS + 4;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * 256;
+    if (kcontig) {
+      const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
+      s[(k4 + 0) * LD + r] = t.v[i].x;
+      s[(k4 + 1) * LD + r] = t.v[i].y;
+      s[(k4 + 2) * LD + r] = t.v[i].z;
+      s[(k4 + 3) * LD + r] = t.v[i].w;
+    } else {
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      *reinterpret_cast<float4*>(&s[k * LD + r4]) = t.v[i];
+    }
+  }
+}
+
+__device__ __forceinline__ float act_mask_factor(float h, int act, bool keep, float scale) {
+  // d out / d pre for out = dropout(act(pre)) given the stored out value h
+  if (!keep) return 0.f;
+  if (act == HMP_ACT_RELU) return h > 0.f ? scale : 0.f;
+  if (act == HMP_ACT_ELU) return h > 0.f ? scale : (h + scale);  // elu'(pre) = elu(pre) + 1 for pre <= 0
+  return scale;
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, KW = 4 / (WM * WN);
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int STAGE = BK * LDA + BK * LDB;
+  constexpr int RED = (KW > 1) ? (KW - 1) * 16 * 64 : 0;
+  constexpr int SMEM = STAGE > RED ? STAGE : RED;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* As = smem;
+  float* Bs = smem + BK * LDA;
+
+  int pi = 0;
+  while (pi + 1 < gb.n && (int)blockIdx.x >= gb.p[pi + 1].tile_start) ++pi;
+  const GemmProblem& P = gb.p[pi];
+  const int local = blockIdx.x - P.tile_start;
+  const int tiles_mn = P.tiles_m * P.tiles_n;
+  const int z = local / tiles_mn, t = local % tiles_mn;
+  const int m0 = (t % P.tiles_m) * BM, n0 = (t / P.tiles_m) * BN;
+  const int kbeg = z * P.kchunk;
+  const int kend = min(P.K, kbeg + P.kchunk);
+
+  const int a_kcontig = P.trans_a ? 0 : 1;
+  const int b_kcontig = P.trans_b ? 1 : 0;
+  const bool a_vec = ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && (a_kcontig ? (kbeg & 3) == 0 : true);
+  const bool b_vec = ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && (b_kcontig ? (kbeg & 3) == 0 : true);
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w % WM, wn = (w / WM) % WN, kw = w / (WM * WN);
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  TileRegs<BM> ra;
+  TileRegs<BN> rb;
+  // for A the "row" dimension is M (bounds M, no aug); for B it is N (n_real real columns, optional ones column)
+  tile_load<BM>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kbeg, kend, a_vec);
+  tile_load<BN>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kbeg, kend, b_vec);
+
+  for (int kt = kbeg; kt < kend; kt += BK) {
+    tile_store<BM>(ra, As, a_kcontig);
+    tile_store<BN>(rb, Bs, b_kcontig);
+    __syncthreads();
+    if (kt + BK < kend) {
+      tile_load<BM>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kt + BK, kend, a_vec);
+      tile_load<BN>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kt + BK, kend, b_vec);
+    }
+    constexpr int KS = BK / KW;
+    const float* ap = As + (kw * KS + (lane >> 5)) * LDA + wm * 32 + (lane & 31);
+    const float* bp = Bs + (kw * KS + (lane >> 5)) * LDB + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk += 2) {
+      const float a = ap[kk * LDA];
+      const float b = bp[kk * LDB];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  if (KW > 1) {  // fixed-order cross-wave reduction through LDS
+    float* red = smem;
+    if (kw > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[((kw - 1) * 16 + i) * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (kw == 0) {
+#pragma unroll
+      for (int q = 0; q < KW - 1; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += red[(q * 16 + i) * 64 + lane];
+    }
+  }
+  if (kw != 0) return;
+
+  // A = [i][k] supplies the rows of C, B = [k][j] its columns;
+  // D layout: col j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  float* C = P.C + (int64_t)z * P.slab_stride;
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col >= P.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row >= P.M) continue;
+    float v = acc[r];
+    if (P.epi == EPI_ACTMASK) {
+      const float h = P.H[(int64_t)row * P.ldh + col];
+      bool keep = true;
+      float scale = 1.f;
+      if (P.drop_on) {
+        bool k4[4];
+        drop_keep4(drop_resolve(P.drop), (uint32_t)row * (uint32_t)(P.ldh >> 2) + (uint32_t)(col >> 2), k4);
+        keep = k4[col & 3];
+        scale = P.drop.scale;
+      }
+      v *= act_mask_factor(h, P.act, keep, scale);
+    }
+    C[(int64_t)row * P.ldc + col] = v;
+  }
+}
+
+template <int WM, int WN>
+static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  int start = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    GemmProblem& p = gb.p[i];
+    p.tiles_m = cdiv(p.M, BM);
+    p.tiles_n = cdiv(p.N, BN);
+    int tiles = p.tiles_m * p.tiles_n;
+    int ks = 1;
+    if (want_split && tiles > 0) {
+      // aim at ~1024 workgroups overall; every slab gets >= 2 K tiles
+      ks = 1024 / (tiles * gb.n);
+      int max_by_k = cdiv(p.K, 2 * BK);
+      if (ks > max_by_k) ks = max_by_k;
+      if (ks > max_slabs) ks = max_slabs;
+      if (ks < 1) ks = 1;
+    }
+    int kchunk = cdiv(cdiv(p.K, ks), BK) * BK;
+    if (kchunk < BK) kchunk = BK;
+    ks = p.K > 0 ? cdiv(p.K, kchunk) : 1;
+    p.ksplit = ks;
+    p.kchunk = kchunk;
+    p.tile_start = start;
+    start += tiles * ks;
+  }
+  gb.total_tiles = start;
+  if (start == 0) return HMP_OK;
+  hipLaunchKernelGGL((gemm_kernel<WM, WN>), dim3(start), dim3(256), 0, st, gb);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
+  HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm: %d problems", gb.n);
+  // drop empty problems (M, N or K = 0): with K == 0 the output must still be zero-filled
+  int64_t tiles64 = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    const GemmProblem& p = gb.p[i];
+    HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative size");
+    tiles64 += (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
+  }
+  // big problems: 64x64 tiles; small ones: 32x32 tiles with in-block K split
+  if (tiles64 >= 1024) return launch_cfg<2, 2>(gb, want_split, max_slabs, st);
+  return launch_cfg<1, 1>(gb, want_split, max_slabs, st);
+}
+
+}  // namespace hmp
+
+extern "C" int hmp_gemm_f32(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b,
+                            float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(d_a && d_b && d_c, "hmp_gemm_f32: null pointer");
+  HMP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "hmp_gemm_f32: negative size");
+  HMP_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "hmp_gemm_f32: leading dimension too small");
+  GemmBatch gb;
+  memset(&gb, 0, sizeof(gb));
+  gb.n = 1;
+  GemmProblem& p = gb.p[0];
+  p.A = d_a; p.B = d_b; p.C = d_c;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.trans_a = trans_a; p.trans_b = trans_b;
+  p.n_real = N;
+  p.epi = EPI_NONE;
+  if (M == 0 || N == 0) return HMP_OK;
+  return gemm_launch(gb, false, 1, (hipStream_t)stream);
+}

@@ -1,0 +1,206 @@
+// Graph plan: CSR-by-destination and CSC-by-source neighbour lists for every edge type of a batch, built
+// on the device from the PyG `edge_index` (int64 [2][E]) in five short launches that cover ALL edge
+// types and both directions at once (scene-graph batches have 4..15 edge types of 10^2..10^7 edges).
+//
+// Stable order without a sort pass: (1) histogram, (2) exclusive scan, (3) atomic fill into a scratch
+// list (unordered inside a row), (4) one wavefront per row ranks the row's edge ids by counting -- rows
+// are short (scene graphs: mean in-degree ~6, rooms ~10^2) -- and writes them in ascending edge id, which
+// IS the stable order torch.sort(dst, stable=True) gives.  The result is therefore bit-identical from run
+// to run although step (3) uses atomics.  (5) links every CSC entry to its CSR position.
+#include "kernels.h"
+
+namespace hmp {
+
+__device__ __forceinline__ int find_job(const int64_t* start, int n, int64_t g) {
+  int j = 0;
+  while (j + 1 < n && g >= start[j + 1]) ++j;
+  return j;
+}
+
+__global__ __launch_bounds__(256) void plan_hist_kernel(const PlanBatch pb, int* status) {
+  const int64_t total = pb.edge_start[pb.n];
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int j = find_job(pb.edge_start, pb.n, g);
+    const PlanJob& J = pb.j[j];
+    const int64_t e = g - pb.edge_start[j];
+    const int64_t s = J.ei[e], d = J.ei[J.E + e];
+    if (s < 0 || s >= J.n_src || d < 0 || d >= J.n_dst) {
+      if (status) atomicOr(status, 1);
+      continue;
+    }
+    atomicAdd(&J.cnt_in[d], 1);
+    atomicAdd(&J.cnt_out[s], 1);
+  }
+}
+
+// one 1024-thread block per (job, direction): exclusive scan of the counts
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const PlanBatch pb) {
+  const int j = blockIdx.x >> 1, dir = blockIdx.x & 1;
+  const PlanJob& J = pb.j[j];
+  const int n = dir ? J.n_src : J.n_dst;
+  const int* cnt = dir ? J.cnt_out : J.cnt_in;
+  int* ptr = dir ? J.t_rowptr : J.rowptr;
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? cnt[i] : 0;
+    int x = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < w; ++q) woff += wsum[q];
+    const int carry = carry_s;
+    if (i < n) ptr[i] = carry + woff + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[n] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void plan_fill_kernel(const PlanBatch pb) {
+  const int64_t total = pb.edge_start[pb.n];
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int j = find_job(pb.edge_start, pb.n, g);
+    const PlanJob& J = pb.j[j];
+    const int64_t e = g - pb.edge_start[j];
+    const int64_t s = J.ei[e], d = J.ei[J.E + e];
+    if (s < 0 || s >= J.n_src || d < 0 || d >= J.n_dst) continue;
+    const int pi = atomicAdd(&J.cur_in[d], 1);
+    J.tmp_in[J.rowptr[d] + pi] = (int)e;
+    const int po = atomicAdd(&J.cur_out[s], 1);
+    J.tmp_out[J.t_rowptr[s] + po] = (int)e;
+  }
+}
+
+// one wavefront per row of (job, dir); rank-by-counting inside the row
+__global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
+  const int64_t total_rows = pb.row_start[2 * pb.n];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < total_rows; r += n_waves) {
+    const int jd = find_job(pb.row_start, 2 * pb.n, r);
+    const PlanJob& J = pb.j[jd >> 1];
+    const int dir = jd & 1;
+    const int row = (int)(r - pb.row_start[jd]);
+    const int* ptr = dir ? J.t_rowptr : J.rowptr;
+    const int* tmp = dir ? J.tmp_out : J.tmp_in;
+    const int b = ptr[row], deg = ptr[row + 1] - b;
+    for (int c = lane; c < deg; c += 64) {
+      const int mine = tmp[b + c];
+      int rank = 0;
+      for (int i = 0; i < deg; ++i) rank += (tmp[b + i] < mine) ? 1 : 0;
+      const int pos = b + rank;
+      if (dir == 0) {
+        J.eid[pos] = mine;
+        J.col[pos] = (int)J.ei[mine];  // source endpoint
+        J.pos_of_eid[mine] = pos;
+      } else {
+        J.t_eid[pos] = mine;
+        J.t_col[pos] = (int)J.ei[J.E + mine];  // destination endpoint
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void plan_link_kernel(const PlanBatch pb) {
+  const int64_t total = pb.edge_start[pb.n];
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int j = find_job(pb.edge_start, pb.n, g);
+    const PlanJob& J = pb.j[j];
+    const int64_t k = g - pb.edge_start[j];
+    if (k < J.t_rowptr[J.n_src]) J.t_pos[k] = J.pos_of_eid[J.t_eid[k]];
+  }
+}
+
+size_t plan_scratch_ints(int64_t E, int n_src, int n_dst) {
+  // cnt_in, cur_in [n_dst]; cnt_out, cur_out [n_src]; tmp_in, tmp_out, t_eid, pos_of_eid [E]; each 64-int aligned
+  auto a = [](int64_t x) { return (size_t)((x + 63) & ~(int64_t)63); };
+  return 2 * a(n_dst) + 2 * a(n_src) + 4 * a(E);
+}
+
+void plan_carve(PlanJob& job, int* s) {
+  auto a = [](int64_t x) { return (size_t)((x + 63) & ~(int64_t)63); };
+  job.cnt_in = s;  s += a(job.n_dst);
+  job.cur_in = s;  s += a(job.n_dst);
+  job.cnt_out = s; s += a(job.n_src);
+  job.cur_out = s; s += a(job.n_src);
+  job.tmp_in = s;  s += a(job.E);
+  job.tmp_out = s; s += a(job.E);
+  job.t_eid = s;   s += a(job.E);
+  job.pos_of_eid = s;
+}
+
+int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
+  HMP_CHECK_ARG(pb.n >= 0 && pb.n <= HMP_MAX_EDGE_TYPES, "plan: %d jobs", pb.n);
+  if (pb.n == 0) return HMP_OK;
+  pb.edge_start[0] = 0;
+  pb.row_start[0] = 0;
+  for (int j = 0; j < pb.n; ++j) {
+    PlanJob& J = pb.j[j];
+    HMP_CHECK_ARG(J.E >= 0 && J.E < (int64_t)2147483647 && J.n_src >= 0 && J.n_dst >= 0, "plan: bad sizes");
+    HMP_CHECK_ARG(J.E == 0 || J.ei != nullptr, "plan: null edge_index with E > 0");
+    pb.edge_start[j + 1] = pb.edge_start[j] + J.E;
+    pb.row_start[2 * j + 1] = pb.row_start[2 * j] + J.n_dst;
+    pb.row_start[2 * j + 2] = pb.row_start[2 * j + 1] + J.n_src;
+    // counters + cursors of one job are one contiguous block (see plan_carve)
+    const size_t zero_ints = (size_t)(J.tmp_in - J.cnt_in);
+    if (zero_ints > 0) HMP_HIP(hipMemsetAsync(J.cnt_in, 0, zero_ints * sizeof(int), st));
+  }
+  const int64_t E = pb.edge_start[pb.n];
+  const int64_t rows = pb.row_start[2 * pb.n];
+  const int eg = (int)(E > 0 ? (cdiv(E, 256) < 2048 ? cdiv(E, 256) : 2048) : 1);
+  if (E > 0) {
+    hipLaunchKernelGGL(plan_hist_kernel, dim3(eg), dim3(256), 0, st, pb, d_status);
+    HMP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(2 * pb.n), dim3(1024), 0, st, pb);
+  HMP_LAUNCH_CHECK();
+  if (E > 0) {
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(eg), dim3(256), 0, st, pb);
+    HMP_LAUNCH_CHECK();
+    const int64_t want = cdiv(rows, 4);
+    const int rg = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    hipLaunchKernelGGL(plan_rank_kernel, dim3(rg), dim3(256), 0, st, pb);
+    HMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(plan_link_kernel, dim3(eg), dim3(256), 0, st, pb);
+    HMP_LAUNCH_CHECK();
+  }
+  return HMP_OK;
+}
+
+}  // namespace hmp
+
+extern "C" size_t hmp_plan_scratch_bytes(int64_t n_edges, int32_t n_src, int32_t n_dst) {
+  return hmp::plan_scratch_ints(n_edges, n_src, n_dst) * sizeof(int);
+}
+
+extern "C" int hmp_plan_build(const int64_t* d_edge_index, hmp_plan plan, void* d_scratch, int32_t* d_status, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(plan.d_rowptr && plan.d_t_rowptr, "hmp_plan_build: null rowptr");
+  HMP_CHECK_ARG(plan.n_edges == 0 || (plan.d_col && plan.d_eid && plan.d_t_col && plan.d_t_pos && d_scratch),
+                "hmp_plan_build: null output/scratch with E > 0");
+  PlanBatch pb;
+  memset(&pb, 0, sizeof(pb));
+  pb.n = 1;
+  PlanJob& J = pb.j[0];
+  J.ei = d_edge_index;
+  J.E = plan.n_edges;
+  J.n_src = plan.n_src;
+  J.n_dst = plan.n_dst;
+  J.rowptr = plan.d_rowptr; J.col = plan.d_col; J.eid = plan.d_eid;
+  J.t_rowptr = plan.d_t_rowptr; J.t_col = plan.d_t_col; J.t_pos = plan.d_t_pos;
+  HMP_CHECK_ARG(d_scratch != nullptr, "hmp_plan_build: scratch required");
+  plan_carve(J, (int*)d_scratch);
+  return plan_launch(pb, d_status, (hipStream_t)stream);
+}

@@ -1,0 +1,180 @@
+"""ctypes binding of ``libhydra_mp.so`` (C ABI declared in ``include/hydra_mp.h``).
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 device is
+visible, :func:`load` / :func:`require_device` raise and every model/op built on them fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhydra_mp.so")
+
+MAX_NODE_TYPES, MAX_EDGE_TYPES, MAX_LAYERS, MAX_CONVS = 8, 16, 8, 16
+N_KCLASS = 12
+KCLASS_NAMES = ["plan", "pack", "gemm_fwd", "aggregate_fwd", "loss", "aggregate_bwd", "gemm_bwd", "grad_reduce",
+                "adam", "gat_fwd", "gat_bwd", "pool"]
+CONV_SAGE, CONV_GAT = 0, 1
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+
+
+class Plan(C.Structure):
+    _fields_ = [
+        ("n_src", C.c_int32), ("n_dst", C.c_int32), ("n_edges", C.c_int64),
+        ("d_rowptr", C.c_void_p), ("d_col", C.c_void_p), ("d_eid", C.c_void_p),
+        ("d_t_rowptr", C.c_void_p), ("d_t_col", C.c_void_p), ("d_t_pos", C.c_void_p),
+    ]
+
+
+class GatArgs(C.Structure):
+    _fields_ = [
+        ("heads", C.c_int32), ("channels", C.c_int32), ("self_loops", C.c_int32),
+        ("negative_slope", C.c_float), ("dropout_p", C.c_float),
+        ("seed", C.c_uint64), ("rng_stream", C.c_uint32), ("rng_step", C.c_uint32),
+    ]
+
+
+class ConvSpec(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("edge_type", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32),
+        ("f_out", C.c_int32), ("heads", C.c_int32), ("concat", C.c_int32), ("self_loops", C.c_int32),
+        ("edge_dim", C.c_int32), ("fill_mean", C.c_int32), ("shared_lin", C.c_int32), ("active", C.c_int32),
+        ("w0", C.c_int64), ("w1", C.c_int64), ("w2", C.c_int64), ("a0", C.c_int64), ("a1", C.c_int64),
+        ("a2", C.c_int64), ("b0", C.c_int64),
+    ]
+
+
+class LayerSpec(C.Structure):
+    _fields_ = [
+        ("n_convs", C.c_int32), ("act", C.c_int32), ("dropout", C.c_float), ("group_mean", C.c_int32),
+        ("out_dim", C.c_int32 * MAX_NODE_TYPES),
+        ("convs", ConvSpec * MAX_CONVS),
+    ]
+
+
+class NetSpec(C.Structure):
+    _fields_ = [
+        ("n_node_types", C.c_int32), ("n_edge_types", C.c_int32), ("n_layers", C.c_int32),
+        ("in_dim", C.c_int32 * MAX_NODE_TYPES),
+        ("edge_src", C.c_int32 * MAX_EDGE_TYPES), ("edge_dst", C.c_int32 * MAX_EDGE_TYPES),
+        ("readout_type", C.c_int32), ("pool_edge_type", C.c_int32),
+        ("n_params", C.c_int64), ("n_active_params", C.c_int64),
+        ("layers", LayerSpec * MAX_LAYERS),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32 * MAX_NODE_TYPES),
+        ("d_x", C.c_void_p * MAX_NODE_TYPES),
+        ("ldx", C.c_int32 * MAX_NODE_TYPES),
+        ("n_edges", C.c_int64 * MAX_EDGE_TYPES),
+        ("d_edge_index", C.c_void_p * MAX_EDGE_TYPES),
+        ("d_edge_attr", C.c_void_p * MAX_EDGE_TYPES),
+        ("n_out", C.c_int32),
+        ("d_labels", C.c_void_p),
+    ]
+
+
+class TrainArgs(C.Structure):
+    _fields_ = [
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+        ("ignored_label", C.c_int64), ("seed", C.c_uint64), ("training", C.c_int32),
+    ]
+
+
+_STRUCTS = [Plan, GatArgs, ConvSpec, LayerSpec, NetSpec, Batch, TrainArgs]
+
+_VP, _I32, _I64, _F32, _U64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32
+
+# name -> (restype, argtypes).  Kept in the order of include/hydra_mp.h; tests/test_abi.py checks that
+# every function the header declares is listed here and exported by the library.
+SIGNATURES = {
+    "hmp_abi_version": (C.c_int, []),
+    "hmp_last_error": (C.c_char_p, []),
+    "hmp_sizeof": (C.c_size_t, [C.c_int]),
+    "hmp_device_count": (C.c_int, []),
+    "hmp_plan_scratch_bytes": (C.c_size_t, [_I64, _I32, _I32]),
+    "hmp_plan_build": (C.c_int, [_VP, Plan, _VP, _VP, _VP]),
+    "hmp_segment_mean_fwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
+    "hmp_segment_mean_bwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
+    "hmp_gemm_f32": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "hmp_gat_fwd": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, Plan, GatArgs, _VP, _VP, _I32, _VP]),
+    "hmp_gat_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _VP, _VP, _VP, _VP, Plan, GatArgs, _VP, _VP, _I32, _VP, _VP,
+                              _VP, _VP, _VP]),
+    "hmp_masked_ce": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, _VP, _I32, _VP, _VP]),
+    "hmp_adam_flat": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _VP, _VP]),
+    "hmp_dropout_mask": (C.c_int, [_U64, _U32, _U32, _F32, _I32, _I32, _VP, _VP]),
+    "hmp_net_create": (C.c_int, [C.POINTER(NetSpec), C.POINTER(_VP)]),
+    "hmp_net_destroy": (None, [_VP]),
+    "hmp_net_workspace_bytes": (C.c_size_t, [_VP, C.POINTER(_I32), C.POINTER(_I64)]),
+    "hmp_net_bind_workspace": (C.c_int, [_VP, _VP, C.c_size_t, C.POINTER(_I32), C.POINTER(_I64)]),
+    "hmp_net_forward": (C.c_int, [_VP, C.POINTER(Batch), _VP, _I32, _U64, _U32, C.POINTER(_VP), C.POINTER(_I32), _VP]),
+    "hmp_net_backward": (C.c_int, [_VP, _VP, _I32, _VP, _VP, C.POINTER(_VP), _VP]),
+    "hmp_net_step_fwd_bwd": (C.c_int, [_VP, C.POINTER(Batch), _VP, _VP, C.POINTER(TrainArgs), _VP]),
+    "hmp_net_step_adam": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(TrainArgs), _VP]),
+    "hmp_net_read_state": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32), _VP]),
+    "hmp_graph_begin": (C.c_int, [_VP]),
+    "hmp_graph_end": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "hmp_graph_launch": (C.c_int, [_VP, _VP]),
+    "hmp_graph_destroy": (None, [_VP]),
+    "hmp_timer_create": (C.c_int, [C.POINTER(_VP)]),
+    "hmp_timer_start": (C.c_int, [_VP, _VP]),
+    "hmp_timer_stop": (C.c_int, [_VP, _VP]),
+    "hmp_timer_elapsed_ms": (C.c_int, [_VP, C.POINTER(_F32)]),
+    "hmp_timer_destroy": (None, [_VP]),
+    "hmp_net_profile": (C.c_int, [_VP, _I32]),
+    "hmp_net_profile_read": (C.c_int, [_VP, C.POINTER(_F32), C.POINTER(_I32)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class HydraMPError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (no GPU needed for this step) and bind every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HydraMPError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hydra-gnn_amd/csrc`.  hydra_gnn_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hmp_abi_version() != 1:
+        raise HydraMPError(f"ABI version mismatch: library {lib.hmp_abi_version()}, binding 1")
+    for i, st in enumerate(_STRUCTS):
+        if lib.hmp_sizeof(i) != C.sizeof(st):
+            raise HydraMPError(f"struct layout mismatch for {st.__name__}: C {lib.hmp_sizeof(i)} vs ctypes {C.sizeof(st)}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().hmp_last_error()
+        raise HydraMPError(f"libhydra_mp error {rc}: {msg.decode() if msg else '?'}")
+
+
+def require_device() -> C.CDLL:
+    lib = load()
+    if lib.hmp_device_count() < 1:
+        raise HydraMPError("no gfx950 (MI355X) device visible: hydra_gnn_amd has no CPU fallback")
+    return lib
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream (torch is the device-memory / stream plumbing)."""
+    import torch
+
+    return int(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,455 @@
+"""Host side of the native network executor (``hmp_net_*`` in ``include/hydra_mp.h``).
+
+:class:`NativeNet` turns a model description (node/edge types, per-layer convs with their
+``nn.Parameter`` objects) into an ``hmp_net_spec``, keeps all parameters in ONE flat fp32 buffer
+(the named parameters are views into it, so ``state_dict()`` keeps the reference's PyG keys while
+the optimiser / all-reduce see one contiguous tensor), owns the device workspace and exposes
+
+* ``forward(data)`` -- autograd-compatible (one ``torch.autograd.Function`` around
+  ``hmp_net_forward`` / ``hmp_net_backward``), so the reference's training loop
+  (``loss.backward(); opt.step()``, ``src/hydra_gnn/base_training_job.py:202-216``) works unchanged;
+* :class:`TrainStep` -- the same loop body as two native phases (fwd+loss+bwd, Adam) captured in
+  hipGraphs, with one flat gradient all-reduce between them for data parallelism.
+
+torch is used for device memory, streams and ``torch.distributed`` only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, CONV_GAT, CONV_SAGE
+
+EdgeType = Tuple[str, str, str]
+
+
+class ConvDesc:
+    """One conv of one layer: kind, edge type and its parameters (by role)."""
+
+    def __init__(self, kind: int, edge_type: EdgeType, f_out: int, params: Dict[str, Optional[nn.Parameter]], **gat):
+        self.kind, self.edge_type, self.f_out, self.params = kind, tuple(edge_type), f_out, params
+        self.gat = gat  # heads, concat, self_loops, edge_dim, fill_mean, shared_lin
+        self.active = True
+
+
+class LayerDesc:
+    def __init__(self, convs: List[ConvDesc], out_dims: Dict[str, int], act: int, dropout: float, group_mean: bool = False):
+        self.convs, self.out_dims, self.act, self.dropout, self.group_mean = convs, out_dims, act, dropout, group_mean
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.HydraMPError(
+            f"{what} is on {t.device}: hydra_gnn_amd runs on MI355X (cuda/HIP device) only and has no CPU fallback"
+        )
+
+
+class _BatchHolder:
+    """ctypes batch descriptor + the tensors it points at (kept alive while kernels run)."""
+
+    def __init__(self):
+        self.c = _lib.Batch()
+        self.keep: List[torch.Tensor] = []
+        self.n_nodes: List[int] = []
+        self.n_edges: List[int] = []
+
+
+class NativeNet:
+    def __init__(self, node_types: Sequence[str], in_dims: Dict[str, int], edge_types: Sequence[EdgeType],
+                 layers: List[LayerDesc], readout: str, pool_edge_type: Optional[EdgeType] = None,
+                 count_types: Sequence[str] = ()):
+        self.node_types = list(node_types)
+        self.edge_types = [tuple(e) for e in edge_types]
+        self.in_dims = dict(in_dims)
+        self.layers = layers
+        self.readout = readout
+        self.pool_edge_type = tuple(pool_edge_type) if pool_edge_type is not None else None
+        # node types without features whose node COUNT matters (virtual pool targets)
+        self.count_types = list(count_types)
+        assert len(self.node_types) <= _lib.MAX_NODE_TYPES and len(self.edge_types) <= _lib.MAX_EDGE_TYPES
+        self._mark_liveness()
+        self._layout_params()
+        self._handle = None
+        self._ws = None
+        self._caps = None
+        self._flat: Optional[torch.Tensor] = None
+        self._lib = None
+        self._fwd_token = 0
+
+    # ---- static analysis ---------------------------------------------------------------------
+    def _mark_liveness(self) -> None:
+        """A conv is live iff its output can reach the readout (reference computes the others and
+        throws them away: heterogeneous_network.py:121-122).  Dead convs keep their parameters
+        (state_dict compatible) but receive no gradient, exactly like ``grad is None`` in torch."""
+        needed = {self.readout}
+        for layer in reversed(self.layers):
+            nxt = set()
+            for conv in layer.convs:
+                s, _, t = conv.edge_type
+                conv.active = t in needed
+                if conv.active:
+                    nxt.update((s, t))
+            needed = nxt
+
+    def _layout_params(self) -> None:
+        roles = ("w0", "w1", "w2", "a0", "a1", "a2", "b0")
+        seen: Dict[int, int] = {}
+        order: List[Tuple[nn.Parameter, bool]] = []
+        for active_pass in (True, False):
+            for layer in self.layers:
+                for conv in layer.convs:
+                    for r in roles:
+                        p = conv.params.get(r)
+                        if p is None or id(p) in seen:
+                            continue
+                        live = conv.active and self._role_used(conv, r)
+                        if live != active_pass:
+                            continue
+                        seen[id(p)] = len(order)
+                        order.append((p, live))
+        # a parameter shared by several convs (GAT lin_src == lin_dst) is active if any user is
+        off = 0
+        self.param_offsets: Dict[int, int] = {}
+        self.params: List[nn.Parameter] = []
+        self.param_active: List[bool] = []
+        for p, live in order:
+            self.param_offsets[id(p)] = off
+            self.params.append(p)
+            self.param_active.append(live)
+            off += ((p.numel() + 3) // 4) * 4  # keep every tensor 16-byte aligned in the flat buffer
+            if live:
+                self.n_active = off
+        if not any(self.param_active):
+            self.n_active = 0
+        self.n_params = off
+
+    @staticmethod
+    def _role_used(conv: ConvDesc, role: str) -> bool:
+        if conv.kind == CONV_SAGE:
+            return role in ("w0", "b0", "w1")
+        # GAT: lin_dst of a same-type conv built from a tuple is never used
+        s, _, t = conv.edge_type
+        if role == "w1" and s == t and not conv.gat.get("shared_lin", False):
+            return False
+        return True
+
+    # ---- native objects ------------------------------------------------------------------------
+    def _spec(self) -> _lib.NetSpec:
+        sp = _lib.NetSpec()
+        nt = {t: i for i, t in enumerate(self.node_types)}
+        et = {e: i for i, e in enumerate(self.edge_types)}
+        sp.n_node_types, sp.n_edge_types, sp.n_layers = len(self.node_types), len(self.edge_types), len(self.layers)
+        for t, i in nt.items():
+            sp.in_dim[i] = int(self.in_dims.get(t, 0))
+        for e, i in et.items():
+            sp.edge_src[i], sp.edge_dst[i] = nt[e[0]], nt[e[2]]
+        sp.readout_type = nt[self.readout]
+        sp.pool_edge_type = et[self.pool_edge_type] if self.pool_edge_type is not None else -1
+        sp.n_params, sp.n_active_params = self.n_params, self.n_active
+        for l, layer in enumerate(self.layers):
+            ls = sp.layers[l]
+            ls.n_convs, ls.act, ls.dropout, ls.group_mean = len(layer.convs), layer.act, float(layer.dropout), int(layer.group_mean)
+            for t, i in nt.items():
+                ls.out_dim[i] = int(layer.out_dims.get(t, 0))
+            for c, conv in enumerate(layer.convs):
+                cs = ls.convs[c]
+                cs.kind, cs.edge_type = conv.kind, et[conv.edge_type]
+                cs.src, cs.dst, cs.f_out = nt[conv.edge_type[0]], nt[conv.edge_type[2]], conv.f_out
+                cs.heads = int(conv.gat.get("heads", 1))
+                cs.concat = int(conv.gat.get("concat", 0))
+                cs.self_loops = int(conv.gat.get("self_loops", 0))
+                cs.edge_dim = int(conv.gat.get("edge_dim", 0) or 0)
+                cs.fill_mean = int(conv.gat.get("fill_mean", 0))
+                cs.shared_lin = int(conv.gat.get("shared_lin", 0))
+                cs.active = int(conv.active)
+                for r in ("w0", "w1", "w2", "a0", "a1", "a2", "b0"):
+                    p = conv.params.get(r)
+                    setattr(cs, r, self.param_offsets[id(p)] if p is not None else -1)
+        return sp
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            self._lib = _lib.require_device()
+            h = C.c_void_p()
+            sp = self._spec()
+            _lib.check(self._lib.hmp_net_create(C.byref(sp), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None and self._lib is not None:
+                self._lib.hmp_net_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ---- flat parameters -------------------------------------------------------------------------
+    def flat_params(self) -> torch.Tensor:
+        """The flat fp32 buffer the named parameters are views of (re-created after ``.to()``)."""
+        p0 = self.params[0]
+        _require_cuda(p0.data, "model parameters")
+        ok = self._flat is not None and self._flat.device == p0.device
+        if ok:
+            base = self._flat.data_ptr()
+            for p in self.params:
+                if p.data.data_ptr() != base + 4 * self.param_offsets[id(p)] or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if not ok:
+            flat = torch.zeros(self.n_params + 4, dtype=torch.float32, device=p0.device)
+            for p in self.params:
+                if p.dtype != torch.float32:
+                    raise _lib.HydraMPError("hydra_gnn_amd computes in fp32: parameter dtype must be float32")
+                off = self.param_offsets[id(p)]
+                view = flat[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+            self._flat = flat
+        return self._flat
+
+    # ---- batch + workspace -------------------------------------------------------------------------
+    def make_batch(self, data, labels: Optional[torch.Tensor] = None) -> _BatchHolder:
+        h = _BatchHolder()
+        x_dict = data.x_dict
+        ei_dict = data.edge_index_dict
+        for i, t in enumerate(self.node_types):
+            if t in x_dict and self.in_dims.get(t, 0) > 0:
+                x = x_dict[t]
+                _require_cuda(x, f"x_dict['{t}']")
+                if x.dtype != torch.float32 or x.stride(-1) != 1 or (x.dim() == 2 and x.size(0) > 1 and x.stride(0) < x.size(1)):
+                    x = x.to(torch.float32).contiguous()
+                if x.size(1) != self.in_dims[t]:
+                    raise _lib.HydraMPError(f"x_dict['{t}'] has {x.size(1)} features, model expects {self.in_dims[t]}")
+                h.keep.append(x)
+                h.c.n_nodes[i] = x.size(0)
+                h.c.d_x[i] = x.data_ptr()
+                h.c.ldx[i] = x.stride(0) if x.size(0) > 1 else x.size(1)
+            else:
+                h.c.n_nodes[i] = int(data[t].num_nodes) if t in self.count_types or t in x_dict else 0
+            h.n_nodes.append(int(h.c.n_nodes[i]))
+        for i, e in enumerate(self.edge_types):
+            if e in ei_dict:
+                ei = ei_dict[e]
+                _require_cuda(ei, f"edge_index_dict[{e}]")
+                if ei.dtype != torch.int64 or not ei.is_contiguous():
+                    ei = ei.to(torch.int64).contiguous()
+                h.keep.append(ei)
+                h.c.n_edges[i] = ei.size(1)
+                h.c.d_edge_index[i] = ei.data_ptr() if ei.size(1) > 0 else None
+            else:
+                h.c.n_edges[i] = 0  # absent edge type == no edges: convs over it contribute root/bias only
+            h.n_edges.append(int(h.c.n_edges[i]))
+        nt = {t: i for i, t in enumerate(self.node_types)}
+        out_type = self.pool_edge_type[2] if self.pool_edge_type is not None else self.readout
+        h.c.n_out = h.n_nodes[nt[out_type]]
+        if labels is not None:
+            _require_cuda(labels, "labels")
+            lab = labels.to(torch.int64).contiguous()
+            if lab.numel() != h.c.n_out:
+                raise _lib.HydraMPError(f"{lab.numel()} labels for {h.c.n_out} output rows")
+            h.keep.append(lab)
+            h.c.d_labels = lab.data_ptr()
+        return h
+
+    def _ensure_workspace(self, h: _BatchHolder, device) -> None:
+        handle = self._ensure_handle()
+        need_n, need_e = h.n_nodes, h.n_edges
+        if self._caps is not None and self._ws is not None and self._ws.device == device:
+            cn, ce = self._caps
+            if all(a <= b for a, b in zip(need_n, cn)) and all(a <= b for a, b in zip(need_e, ce)):
+                return
+            need_n = [max(a, b) for a, b in zip(need_n, cn)]
+            need_e = [max(a, b) for a, b in zip(need_e, ce)]
+        cn = [max(1, int(v)) for v in need_n]
+        ce = [max(1, int(v)) for v in need_e]
+        cn_c = (C.c_int32 * len(cn))(*cn)
+        ce_c = (C.c_int64 * len(ce))(*ce)
+        nbytes = int(self._lib.hmp_net_workspace_bytes(handle, cn_c, ce_c))
+        torch.cuda.synchronize(device)
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(self._lib.hmp_net_bind_workspace(handle, self._ws.data_ptr(), nbytes, cn_c, ce_c))
+        self._caps = (cn, ce)
+
+    def _ws_view(self, ptr: int, rows: int, ld: int) -> torch.Tensor:
+        off = ptr - self._ws.data_ptr()
+        assert 0 <= off and off + rows * ld * 4 <= self._ws.numel() and off % 4 == 0
+        return self._ws[off:off + rows * ld * 4].view(torch.float32).view(rows, ld)
+
+    # ---- autograd-compatible forward -------------------------------------------------------------
+    def forward(self, data, training: bool, seed: int = 0, rng_step: int = 0) -> torch.Tensor:
+        flat = self.flat_params()
+        h = self.make_batch(data)
+        with torch.cuda.device(flat.device):
+            self._ensure_workspace(h, flat.device)
+            return _NetFunction.apply(self, h, bool(training), int(seed), int(rng_step), *self.params)
+
+    def _forward_raw(self, h: _BatchHolder, training: bool, seed: int, rng_step: int) -> torch.Tensor:
+        out_p, ld = C.c_void_p(), C.c_int32()
+        _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), self._flat.data_ptr(), int(training), seed, rng_step,
+                                             C.byref(out_p), C.byref(ld), _lib.stream_ptr()))
+        self._fwd_token += 1
+        return self._ws_view(out_p.value, int(h.c.n_out), ld.value).clone()
+
+    def _backward_raw(self, gout: torch.Tensor) -> torch.Tensor:
+        grads = torch.zeros(self.n_params + 4, dtype=torch.float32, device=gout.device)
+        _lib.check(self._lib.hmp_net_backward(self._handle, gout.data_ptr(), gout.stride(0), self._flat.data_ptr(),
+                                              grads.data_ptr(), None, _lib.stream_ptr()))
+        return grads
+
+    def read_state(self) -> Tuple[int, int]:
+        step, status = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.hmp_net_read_state(self._handle, C.byref(step), C.byref(status), _lib.stream_ptr()))
+        return step.value, status.value
+
+
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: NativeNet, holder: _BatchHolder, training: bool, seed: int, rng_step: int, *params):
+        out = net._forward_raw(holder, training, seed, rng_step)
+        ctx.net, ctx.holder, ctx.token = net, holder, net._fwd_token
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        if ctx.token != net._fwd_token:
+            raise _lib.HydraMPError(
+                "backward() after another forward() of the same model: the native executor keeps the "
+                "activations of the LAST forward only (one forward, then its backward)"
+            )
+        gout = gout.contiguous()
+        if gout.stride(0) % 4 != 0 or gout.data_ptr() % 16 != 0:
+            padded = torch.zeros(gout.size(0), ((gout.size(1) + 3) // 4) * 4, dtype=gout.dtype, device=gout.device)
+            padded[:, : gout.size(1)] = gout
+            gout = padded
+        flat_g = net._backward_raw(gout)
+        grads = []
+        for p, live in zip(net.params, net.param_active):
+            if not live:
+                grads.append(None)
+                continue
+            off = net.param_offsets[id(p)]
+            grads.append(flat_g[off:off + p.numel()].view(p.shape))
+        return (None, None, None, None, None, *grads)
+
+
+class TrainStep:
+    """The loop body of ``BaseTrainingJob.train`` (``base_training_job.py:202-216``) as native code:
+    phase A = plan + forward + masked CE + backward, [all-reduce], phase B = Adam.
+
+    Gradients are SUMS over valid labels; ``{loss_sum, count}`` ride in the tail of the same flat
+    buffer, so one all-reduce(sum) of ``n_active + 2`` floats makes the N-rank update equal to the
+    single-process full-batch update (count-weighted mean), and every rank applies the identical Adam.
+    """
+
+    def __init__(self, net: NativeNet, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                 ignored_label: int = 25, seed: int = 0, training: bool = True, use_graph: bool = True,
+                 process_group=None):
+        self.net = net
+        self.args = _lib.TrainArgs(lr, betas[0], betas[1], eps, weight_decay, ignored_label, seed, int(training))
+        self.use_graph = use_graph
+        self.pg = process_group
+        self._graphs = None
+        self._key = None
+        self._stream = None
+        self.flat = net.flat_params()
+        dev = self.flat.device
+        n = net.n_params + 4
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._holder = None
+
+    def _world(self) -> int:
+        if self.pg is None:
+            return 1
+        import torch.distributed as dist
+
+        return dist.get_world_size(self.pg if self.pg is not True else None)
+
+    def _all_reduce(self) -> None:
+        if self._world() > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.grads[: self.net.n_active + 2], op=dist.ReduceOp.SUM,
+                            group=None if self.pg is True else self.pg)
+
+    def _phase_a(self, h, st):
+        net = self.net
+        _lib.check(net._lib.hmp_net_step_fwd_bwd(net._handle, C.byref(h.c), self.flat.data_ptr(), self.grads.data_ptr(),
+                                                 C.byref(self.args), st))
+
+    def _phase_b(self, st):
+        net = self.net
+        _lib.check(net._lib.hmp_net_step_adam(net._handle, self.flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                                              self.v.data_ptr(), C.byref(self.args), st))
+
+    def __call__(self, data, labels: torch.Tensor) -> None:
+        net = self.net
+        if net.flat_params() is not self.flat:
+            raise _lib.HydraMPError("model parameters were moved after TrainStep was created")
+        h = net.make_batch(data, labels)
+        dev = self.flat.device
+        with torch.cuda.device(dev):
+            net._ensure_workspace(h, dev)
+            if not self.use_graph:
+                st = _lib.stream_ptr()
+                self._phase_a(h, st)
+                self._all_reduce()
+                self._phase_b(st)
+                self._holder = h
+                return
+            key = (tuple(h.n_nodes), tuple(h.n_edges), tuple(t.data_ptr() for t in h.keep), id(net._ws))
+            if self._graphs is None or key != self._key:
+                self._capture(h, key)
+            ga, gb = self._graphs
+            cur = torch.cuda.current_stream()
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                st = _lib.stream_ptr()
+                _lib.check(net._lib.hmp_graph_launch(ga, st))
+                self._all_reduce()
+                _lib.check(net._lib.hmp_graph_launch(gb, st))
+            cur.wait_stream(self._stream)
+
+    def _capture(self, h, key) -> None:
+        net = self.net
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.flat.device)
+        self._destroy_graphs()
+        torch.cuda.synchronize(self.flat.device)
+        with torch.cuda.stream(self._stream):
+            st = _lib.stream_ptr()
+            ga, gb = C.c_void_p(), C.c_void_p()
+            _lib.check(net._lib.hmp_graph_begin(st))
+            try:
+                self._phase_a(h, st)
+            finally:
+                _lib.check(net._lib.hmp_graph_end(st, C.byref(ga)))
+            _lib.check(net._lib.hmp_graph_begin(st))
+            try:
+                self._phase_b(st)
+            finally:
+                _lib.check(net._lib.hmp_graph_end(st, C.byref(gb)))
+        self._graphs, self._key, self._holder = (ga, gb), key, h
+
+    def _destroy_graphs(self) -> None:
+        if self._graphs is not None:
+            for g in self._graphs:
+                self.net._lib.hmp_graph_destroy(g)
+            self._graphs = None
+
+    def __del__(self):
+        try:
+            self._destroy_graphs()
+        except Exception:
+            pass
+
+    def loss(self) -> float:
+        """mean CE over the valid labels of the last step (global when data parallel); synchronises."""
+        t = self.grads[self.net.n_active: self.net.n_active + 2].tolist()
+        return t[0] / max(t[1], 1.0)

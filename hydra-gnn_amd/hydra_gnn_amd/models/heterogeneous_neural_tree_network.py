@@ -1,0 +1,106 @@
+"""``HeterogeneousNeuralTreeNetwork`` -- drop-in for the reference's
+``src/hydra_gnn/models/heterogeneous_neural_tree_network.py:34-205`` on the MI355X engine.
+
+Message passing over the 10 ``HTREE_EDGE_TYPES`` of an augmented H-tree, then ``LeafPool`` (mean of the
+``room`` leaves of every ``room_virtual`` node, reference :18-31,182-185) -- all inside one native program
+(the pool is the executor's ``pool_edge_type`` stage).  ``pre_mp`` (GAT initialisation of the clique
+nodes, reference :92-103) is built when ``disable_initialization=False``; every shipped H-tree config
+disables it (``config/mp3d/htree_gt60.yaml:10``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..data import HTREE_EDGE_TYPES, HTREE_INIT_EDGE_TYPES, HTREE_NODE_TYPES
+from ..engine import NativeNet
+from .heterogeneous_network import _NativeModule, _hetero_layers
+from .utils import GATConv, HeteroConv, build_GAT_hetero_conv, build_hetero_conv
+
+POOL_EDGE_TYPE = ("room", "r_to_rv", "room_virtual")
+
+
+class LeafPool(nn.Module):
+    """Parameter-free marker module (keeps ``post_mp`` in the module tree like the reference)."""
+
+    def __init__(self, aggr="mean"):
+        super().__init__()
+        assert aggr == "mean"
+
+
+class HeterogeneousNeuralTreeNetwork(_NativeModule):
+    def __init__(
+        self,
+        input_dim_dict,
+        output_dim=None,
+        output_dim_dict=None,
+        conv_block="GraphSAGE",
+        disable_initialization=False,
+        hidden_dim=None,
+        num_layers=None,
+        GAT_hidden_dims=None,
+        GAT_heads=None,
+        GAT_concats=None,
+        dropout=0.25,
+        **kwargs
+    ):
+        super().__init__()
+        assert conv_block in ["GraphSAGE", "GAT", "GAT_edge"]
+        self.conv_block = conv_block
+        if output_dim is not None:
+            assert output_dim_dict is None
+            self.classification_task = "room"
+            output_dim_dict = {node_type: output_dim for node_type in HTREE_NODE_TYPES}
+        else:
+            assert output_dim_dict is not None
+            raise NotImplementedError(
+                "classification_task='all' belongs to the semi-supervised Stanford job (SURVEY.md section 2, row 8)")
+        self.num_layers = num_layers if conv_block[:3] != "GAT" else len(GAT_heads)
+        self.dropout = dropout
+
+        assert input_dim_dict["object"] == input_dim_dict["object_virtual"]
+        assert input_dim_dict["room"] == input_dim_dict["room_virtual"]
+        assert input_dim_dict["object-room"] == input_dim_dict["room-room"]
+        self.input_dim_dict = dict(input_dim_dict)
+
+        if disable_initialization:
+            self.pre_mp = None
+            print("diable initialization")
+        else:
+            self.pre_mp = HeteroConv(
+                {
+                    (s, r, t): GATConv((input_dim_dict[s], input_dim_dict[t]), input_dim_dict[t], heads=1, concat=False,
+                                       dropout=0.0, add_self_loops=False)
+                    for s, r, t in HTREE_INIT_EDGE_TYPES
+                },
+                aggr="mean",
+            )
+
+        mp_in = {t: input_dim_dict[t] for t in HTREE_NODE_TYPES}
+        hidden = {t: hidden_dim for t in HTREE_NODE_TYPES}
+        if conv_block == "GAT":
+            self.convs = build_GAT_hetero_conv(HTREE_EDGE_TYPES, mp_in, output_dim_dict, GAT_hidden_dims, GAT_heads,
+                                               GAT_concats, dropout)
+        elif conv_block == "GAT_edge":
+            self.convs = build_GAT_hetero_conv(HTREE_EDGE_TYPES, mp_in, output_dim_dict, GAT_hidden_dims, GAT_heads,
+                                               GAT_concats, dropout, edge_dim=3,
+                                               fill_value=torch.zeros(3, dtype=torch.float64))
+        else:
+            dims = [mp_in] + [hidden] * (self.num_layers - 1) + [output_dim_dict]
+            self.convs = nn.ModuleList(
+                build_hetero_conv(conv_block, HTREE_EDGE_TYPES, dims[l], dims[l + 1]) for l in range(self.num_layers))
+        self.post_mp = LeafPool(aggr="mean")
+        self._init_native()
+
+    def _build_native(self) -> NativeNet:
+        if self.pre_mp is not None:
+            raise NotImplementedError("pre_mp clique initialisation is not wired into the native program yet "
+                                      "(set disable_initialization=True as every shipped H-tree config does)")
+        node_types = list(HTREE_NODE_TYPES) + ["room_virtual"]
+        in_dims = {t: self.input_dim_dict[t] for t in HTREE_NODE_TYPES}
+        return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + [POOL_EDGE_TYPE], _hetero_layers(self, node_types),
+                         readout="room", pool_edge_type=POOL_EDGE_TYPE, count_types=["room_virtual"])
+
+    def forward(self, data):
+        out = self._run(data)
+        return out[:, : self.native().layers[-1].out_dims["room"]]

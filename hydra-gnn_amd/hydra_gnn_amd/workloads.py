@@ -1,0 +1,158 @@
+"""Seeded synthetic scene-graph workloads for the BASELINE.json configs.
+
+Real MP3D trajectory graphs and the word2vec table are not available offline, so the bench and the
+parity tests use MP3D-*shaped* graphs: same node/edge types (reference
+``src/hydra_gnn/mp3d_dataset.py:21-26``), same feature contract (objects 306-d =
+pos(3) | bbox size(3) | semantic(300); rooms 6-d; 26 room labels with 25 = ignored,
+``src/hydra_gnn/base_training_job.py:63``), statistics taken from the one real fixture graph
+(5 rooms / 62 objects, mean object in-degree 5.74).
+
+Everything is generated with ``numpy.random.Generator(PCG64(seed))`` so the same seed gives the
+same graphs here and on the GPU box.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .data import EDGE_TYPES, Data, HeteroData, collate, compute_relative_pos
+
+BASE_SEED = 20250225
+NUM_ROOM_LABELS = 26
+IGNORED_LABEL = 25
+
+
+def _sym_edges(pairs: np.ndarray) -> np.ndarray:
+    """undirected pairs [M,2] -> directed edge_index [2, 2M] with both directions (u->v then v->u)."""
+    if pairs.size == 0:
+        return np.zeros((2, 0), dtype=np.int64)
+    return np.concatenate([pairs.T, pairs[:, ::-1].T], axis=1).astype(np.int64)
+
+
+def mp3d_like_graph(rng: np.random.Generator, sem_dim: int = 300, mean_in_degree: float = 6.0) -> HeteroData:
+    n_rooms = int(rng.integers(2, 13))
+    per_room = np.maximum(rng.poisson(12.0, size=n_rooms), 1)
+    n_obj = int(per_room.sum())
+    room_of = np.repeat(np.arange(n_rooms), per_room)
+    obj_start = np.concatenate([[0], np.cumsum(per_room)])
+
+    # objects <-> objects: within-room undirected pairs, expected in-degree ~ mean_in_degree
+    pairs = []
+    for r in range(n_rooms):
+        k = int(per_room[r])
+        if k < 2:
+            continue
+        n_pairs_all = k * (k - 1) // 2
+        want = min(n_pairs_all, int(round(mean_in_degree * k / 2.0)))
+        iu, ju = np.triu_indices(k, 1)
+        sel = rng.choice(n_pairs_all, size=want, replace=False)
+        sel.sort()
+        pairs.append(np.stack([iu[sel], ju[sel]], 1) + obj_start[r])
+    oo = _sym_edges(np.concatenate(pairs, 0) if pairs else np.zeros((0, 2), dtype=np.int64))
+
+    # rooms <-> rooms: random spanning tree + 20 % extra undirected edges
+    tree = np.array([[int(rng.integers(0, v)), v] for v in range(1, n_rooms)], dtype=np.int64).reshape(-1, 2)
+    extra_n = int(round(0.2 * max(n_rooms - 1, 0)))
+    have = {(int(a), int(b)) for a, b in tree}
+    extra = []
+    tries = 0
+    while len(extra) < extra_n and tries < 50:
+        tries += 1
+        a, b = sorted(int(v) for v in rng.choice(n_rooms, size=2, replace=False))
+        if (a, b) not in have:
+            have.add((a, b))
+            extra.append([a, b])
+    rr_pairs = np.concatenate([tree, np.array(extra, dtype=np.int64).reshape(-1, 2)], 0)
+    rr = _sym_edges(rr_pairs)
+
+    # rooms -> objects: one edge per object; objects -> rooms is the flipped copy
+    # (reference src/hydra_gnn/mp3d_dataset.py:247-249)
+    ro = np.stack([room_of, np.arange(n_obj)], 0).astype(np.int64)
+
+    def feats(n, with_sem):
+        pos = rng.normal(0.0, 5.0, size=(n, 3))
+        size = rng.uniform(0.1, 2.0, size=(n, 3))
+        cols = [pos, size]
+        if with_sem and sem_dim > 0:
+            cols.append(rng.normal(0.0, 0.15, size=(n, sem_dim)))
+        return np.concatenate(cols, 1).astype(np.float32), pos.astype(np.float32)
+
+    xo, po = feats(n_obj, True)
+    xr, pr = feats(n_rooms, False)
+
+    g = HeteroData()
+    g["objects"].x = torch.from_numpy(xo)
+    g["objects"].pos = torch.from_numpy(po)
+    g["objects"].y = torch.from_numpy(rng.integers(0, 28, size=n_obj).astype(np.int64))
+    g["rooms"].x = torch.from_numpy(xr)
+    g["rooms"].pos = torch.from_numpy(pr)
+    g["rooms"].y = torch.from_numpy(rng.integers(0, NUM_ROOM_LABELS, size=n_rooms).astype(np.int64))
+    g["objects", "objects_to_objects", "objects"].edge_index = torch.from_numpy(oo)
+    g["rooms", "rooms_to_rooms", "rooms"].edge_index = torch.from_numpy(rr)
+    g["objects", "objects_to_rooms", "rooms"].edge_index = torch.from_numpy(ro[::-1].copy())
+    g["rooms", "rooms_to_objects", "objects"].edge_index = torch.from_numpy(ro)
+    return g
+
+
+def mp3d_like_batch(batch_size: int, seed: int, relative_pos: bool = False, sem_dim: int = 300) -> HeteroData:
+    """Config 2 (``seed = BASE_SEED + 2``, B=32) and config 3 (``BASE_SEED + 3``, B=64)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    graphs = [mp3d_like_graph(rng, sem_dim=sem_dim) for _ in range(batch_size)]
+    if relative_pos:
+        for g in graphs:
+            compute_relative_pos(g)
+    return collate(graphs)
+
+
+def config2_batch(batch_size: int = 32, rank: int = 0) -> HeteroData:
+    return mp3d_like_batch(batch_size, BASE_SEED + 2 + 1000 * rank)
+
+
+def config3_batch(batch_size: int = 64, rank: int = 0, edge: bool = False) -> HeteroData:
+    return mp3d_like_batch(batch_size, BASE_SEED + 3 + 1000 * rank, relative_pos=edge)
+
+
+def big_hetero_graph(n_obj: int = 1_000_000, n_rooms: int = 10_000, deg: int = 16, feat_dim: int = 256,
+                     seed: int = BASE_SEED + 5, dtype=torch.float32) -> HeteroData:
+    """Config 5: one large hetero graph (object in-neighbours 90 % own room / 10 % global)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    room_of = np.sort(rng.integers(0, n_rooms, size=n_obj)).astype(np.int64)
+    start = np.searchsorted(room_of, np.arange(n_rooms), side="left")
+    count = np.diff(np.concatenate([start, [n_obj]]))
+    dst = np.repeat(np.arange(n_obj, dtype=np.int64), deg)
+    local = rng.random(n_obj * deg) < 0.9
+    r = room_of[dst]
+    src_local = start[r] + (rng.random(n_obj * deg) * np.maximum(count[r], 1)).astype(np.int64)
+    src_glob = rng.integers(0, n_obj, size=n_obj * deg)
+    src = np.where(local, np.minimum(src_local, n_obj - 1), src_glob).astype(np.int64)
+    oo = np.stack([src, dst], 0)
+    ro = np.stack([room_of, np.arange(n_obj, dtype=np.int64)], 0)
+    n_rr = 3 * n_rooms
+    a = rng.integers(0, n_rooms, size=n_rr)
+    b = rng.integers(0, n_rooms, size=n_rr)
+    rr = _sym_edges(np.stack([a, b], 1))
+    g = HeteroData()
+    g["objects"].x = torch.from_numpy(rng.normal(0, 0.5, size=(n_obj, feat_dim)).astype(np.float32)).to(dtype)
+    g["rooms"].x = torch.from_numpy(rng.normal(0, 0.5, size=(n_rooms, feat_dim)).astype(np.float32)).to(dtype)
+    g["rooms"].y = torch.from_numpy(rng.integers(0, NUM_ROOM_LABELS, size=n_rooms).astype(np.int64))
+    g["objects", "objects_to_objects", "objects"].edge_index = torch.from_numpy(oo)
+    g["rooms", "rooms_to_rooms", "rooms"].edge_index = torch.from_numpy(rr)
+    g["objects", "objects_to_rooms", "rooms"].edge_index = torch.from_numpy(ro[::-1].copy())
+    g["rooms", "rooms_to_objects", "objects"].edge_index = torch.from_numpy(ro)
+    g.num_graphs = 1
+    return g
+
+
+def stanford_graph(npz, i: int) -> Data:
+    """Config 1 input: graph ``i`` of the committed Stanford3DSG fixture subset
+    (``tests/golden/stanford3dsg_subset.npz``; layout of reference ``data/Stanford3DSG.pkl``,
+    SURVEY Appendix B.4): room is node 0, x is ``[N, 6]`` float32."""
+    x = torch.from_numpy(npz[f"x_{i}"])
+    return Data(
+        x=x,
+        edge_index=torch.from_numpy(npz[f"edge_index_{i}"]),
+        y=torch.from_numpy(npz[f"y_{i}"]),
+        room_mask=torch.from_numpy(npz[f"room_mask_{i}"]),
+    )

@@ -1,0 +1,266 @@
+/*
+ * hydra_mp.h -- C ABI of libhydra_mp.so, the MI355X (gfx950) message-passing engine that replaces the
+ * torch_geometric layer stack on Hydra-GNN's room-classification hot path.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM) unless stated; sizes are element counts.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - return value: 0 = OK, otherwise an HMP_E_* code; hmp_last_error() gives the message
+ *     (thread local).  No entry point falls back to a CPU path.
+ *   - features are fp32 row-major with an explicit leading dimension (floats); graph indices are
+ *     int32 in the plan, int64 `edge_index[2][E]` on input (the PyG contract: row 0 = source,
+ *     row 1 = destination, aggregation at the destination).
+ *
+ * Each group cites the reference interface it replaces (paths relative to the reference repo;
+ * "[PyG]" = torch_geometric 2.3.1 operator the reference calls, restated in SURVEY.md Appendix A).
+ */
+#ifndef HYDRA_MP_H
+#define HYDRA_MP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMP_ABI_VERSION 1
+
+#define HMP_OK 0
+#define HMP_E_ARG 1      /* bad argument (shape / alignment / capacity) */
+#define HMP_E_HIP 2      /* a HIP runtime call failed */
+#define HMP_E_STATE 3    /* call order violated (e.g. backward without forward) */
+#define HMP_E_NODEVICE 4 /* no gfx950 device visible */
+
+#define HMP_MAX_NODE_TYPES 8
+#define HMP_MAX_EDGE_TYPES 16
+#define HMP_MAX_LAYERS 8
+#define HMP_MAX_CONVS 16 /* per layer */
+
+/* ---------------------------------------------------------------------------------------------
+ * 0. library
+ * ------------------------------------------------------------------------------------------- */
+int hmp_abi_version(void);
+const char* hmp_last_error(void);
+/* sizeof() of the ABI structs: 0 hmp_plan, 1 hmp_gat_args, 2 hmp_conv_spec, 3 hmp_layer_spec, 4 hmp_net_spec,
+ * 5 hmp_batch, 6 hmp_train_args (lets a foreign-language binding verify its struct mirror) */
+size_t hmp_sizeof(int which);
+/* number of visible devices whose gcnArchName starts with "gfx950"; never raises */
+int hmp_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. graph plan: CSR by destination + CSC (transpose) by source, stable in edge order.
+ *    Replaces the per-call `index_select` / `scatter` index handling of
+ *    [PyG] MessagePassing.propagate (called from models/utils.py:14,49 via HeteroConv).
+ *    Bit-exact contract: col[rowptr[i] .. rowptr[i+1]) are the sources of the edges whose
+ *    destination is i, in ascending original edge id (== torch.sort(dst, stable=True)).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hmp_plan {
+  int32_t n_src, n_dst;
+  int64_t n_edges;
+  int32_t* d_rowptr;   /* [n_dst+1]  CSR by destination */
+  int32_t* d_col;      /* [E] source node of the k-th CSR entry */
+  int32_t* d_eid;      /* [E] original edge id of the k-th CSR entry */
+  int32_t* d_t_rowptr; /* [n_src+1]  CSC (edges grouped by source) */
+  int32_t* d_t_col;    /* [E] destination node of the k-th CSC entry */
+  int32_t* d_t_pos;    /* [E] CSR position of the k-th CSC entry (eid = d_eid[d_t_pos[k]]) */
+} hmp_plan;
+
+/* bytes of scratch hmp_plan_build needs for E edges between n_src and n_dst nodes */
+size_t hmp_plan_scratch_bytes(int64_t n_edges, int32_t n_src, int32_t n_dst);
+/* d_edge_index: int64 [2][E] (row stride = E).  Out-of-range endpoints set bit 0 of *d_status
+ * (int32, device, may be NULL) and the edge is dropped from the lists (its slot keeps eid = -1). */
+int hmp_plan_build(const int64_t* d_edge_index, hmp_plan plan, void* d_scratch, int32_t* d_status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. K1 -- segment mean over CSR rows (SAGE neighbour mean, LeafPool).
+ *    Replaces [PyG] SAGEConv.propagate(aggr="mean") = index_select + scatter_add x2 + clamp + div
+ *     and LeafPool (models/heterogeneous_neural_tree_network.py:18-31).
+ *    out[i, 0:F] = (1/max(deg_i,1)) * sum_{k in row i} x[col[k], 0:F]     (zeros for empty rows)
+ *    bwd: g_x[j, 0:F] = sum_{k in CSC row j} g_out[t_col[k], 0:F] / max(deg(t_col[k]),1)
+ * ------------------------------------------------------------------------------------------- */
+int hmp_segment_mean_fwd(const float* d_x, int32_t ldx, int32_t F, hmp_plan plan, float* d_out, int32_t ldo, void* stream);
+int hmp_segment_mean_bwd(const float* d_gout, int32_t ldg, int32_t F, hmp_plan plan, float* d_gx, int32_t ldgx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. K2 -- dense fp32 projection on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain).
+ *    Replaces F.linear inside [PyG] SAGEConv.lin_l / lin_r and GATConv.lin_src / lin_dst.
+ *    C[M,N] = op(A)[M,K] * op(B)[K,N];  trans_a: A stored [K][M];  trans_b: B stored [N][K]
+ *    (trans_b = 1 is nn.Linear's weight layout).
+ * ------------------------------------------------------------------------------------------- */
+int hmp_gemm_f32(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b,
+                 float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 4. K3 -- GAT edge softmax + weighted aggregation, one wavefront group per destination row.
+ *    Replaces [PyG] GATConv.edge_update + softmax + message/aggregate.
+ *    h_src [n_src, H*C] (ld = ldh), a_src [n_src, H], a_dst [n_dst, H]; optional per-edge logit term
+ *    a_edge [E, H] in ORIGINAL edge order (NULL = none).  With self_loops != 0 entries with
+ *    col == row are skipped and one loop edge i->i is appended per row i < min(n_src, n_dst)
+ *    (its a_edge term is d_a_loop [n, H] or 0 when NULL).
+ *    alpha (post-softmax, pre-dropout) is written in CSR order [E + n_loop, H] for the backward.
+ *    out [n_dst, H*C] = sum_k dropout(alpha_k) * h_src[col_k]   (no bias / head-mean here).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hmp_gat_args {
+  int32_t heads, channels;
+  int32_t self_loops;
+  float negative_slope;
+  float dropout_p;           /* attention dropout; 0 = off */
+  uint64_t seed;             /* dropout RNG (Philox4x32-10) */
+  uint32_t rng_stream, rng_step;
+} hmp_gat_args;
+
+int hmp_gat_fwd(const float* d_h_src, int32_t ldh, const float* d_a_src, const float* d_a_dst, const float* d_a_edge,
+                const float* d_a_loop, hmp_plan plan, hmp_gat_args args, float* d_alpha, float* d_out, int32_t ldo,
+                void* stream);
+/* grads: g_h_src [n_src, H*C], g_a_src [n_src, H], g_a_dst [n_dst, H], g_a_edge [E, H] (original edge
+ * order, may be NULL), g_a_loop [n, H] (may be NULL).  d_dlogit is scratch [E + n_loop, H]. */
+int hmp_gat_bwd(const float* d_gout, int32_t ldo, const float* d_h_src, int32_t ldh, const float* d_a_src,
+                const float* d_a_dst, const float* d_a_edge, const float* d_a_loop, const float* d_alpha, hmp_plan plan,
+                hmp_gat_args args, float* d_dlogit, float* d_g_h_src, int32_t ldgh, float* d_g_a_src, float* d_g_a_dst,
+                float* d_g_a_edge, float* d_g_a_loop, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 5. loss + optimiser
+ *    masked cross entropy: models/utils.py:143-148 with mask = (label != ignored_label)
+ *    (base_training_job.py:213-214).  Writes d_out2 = {sum of -log p[label] over valid rows, number of
+ *    valid rows}; d_grad [n, ldg] = (softmax - onehot) for valid rows, 0 otherwise, i.e. the gradient
+ *    of the SUM loss -- callers scale by 1/count (so that N-GPU averaging is count-weighted).
+ *    Adam: torch.optim.Adam(lr, weight_decay) with coupled L2 (base_training_job.py:181-185):
+ *    g = grad*grad_scale + wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ *    p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ * ------------------------------------------------------------------------------------------- */
+int hmp_masked_ce(const float* d_logits, int32_t ldl, int32_t n_rows, int32_t n_classes, const int64_t* d_labels,
+                  int64_t ignored_label, float* d_grad, int32_t ldg, float* d_out2, void* stream);
+/* d_count: device float holding the valid-label count (grad_scale = 1/max(count,1)); NULL => grad_scale = 1 */
+int hmp_adam_flat(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int32_t step, const float* d_count, void* stream);
+
+/* keep-mask generator of the engine's feature dropout, exposed so tests can replay it in the oracle:
+ * element (row, col) of a [n_rows, F] tensor is kept iff mask[row*F+col] != 0. */
+int hmp_dropout_mask(uint64_t seed, uint32_t rng_step, uint32_t rng_stream, float p, int32_t n_rows, int32_t F,
+                     uint8_t* d_mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 6. network executor -- the whole HeteroConv layer stack as one native program.
+ *    Replaces HeterogeneousNetwork.forward (models/heterogeneous_network.py:99-122),
+ *    HeterogeneousNeuralTreeNetwork.forward (models/heterogeneous_neural_tree_network.py:154-185),
+ *    HomogeneousNetwork.forward SAGE/GAT branches (models/homogeneous_network.py:122-139) and, for the
+ *    fused step, the loop body of BaseTrainingJob.train (base_training_job.py:202-216).
+ * ------------------------------------------------------------------------------------------- */
+#define HMP_CONV_SAGE 0
+#define HMP_CONV_GAT 1
+#define HMP_ACT_NONE 0
+#define HMP_ACT_RELU 1
+#define HMP_ACT_ELU 2
+
+typedef struct hmp_conv_spec {
+  int32_t kind;       /* HMP_CONV_* */
+  int32_t edge_type;  /* index into hmp_batch edge arrays */
+  int32_t src, dst;   /* node type indices */
+  int32_t f_out;      /* SAGE: out width; GAT: channels C per head */
+  int32_t heads, concat, self_loops, edge_dim; /* GAT only */
+  int32_t fill_mean;  /* GAT_edge self-loop attr: 1 = per-destination mean, 0 = zeros */
+  int32_t shared_lin; /* GAT built from an int in_channels: lin_dst IS lin_src */
+  int32_t active;     /* 0 = output never reaches the loss: skipped in forward and backward */
+  /* offsets (floats) into the flat parameter buffer, -1 = absent.
+   * SAGE: w0 = lin_l.weight [f_out, f_src], b0 = lin_l.bias [f_out], w1 = lin_r.weight [f_out, f_dst]
+   * GAT : w0 = lin_src.weight [H*C, f_src], w1 = lin_dst.weight [H*C, f_dst], a0 = att_src [H*C],
+   *       a1 = att_dst [H*C], w2 = lin_edge.weight [H*C, edge_dim], a2 = att_edge [H*C], b0 = bias */
+  int64_t w0, w1, w2, a0, a1, a2, b0;
+} hmp_conv_spec;
+
+typedef struct hmp_layer_spec {
+  int32_t n_convs;
+  int32_t act;         /* activation applied to this layer's output (HMP_ACT_NONE on the last) */
+  float dropout;       /* feature dropout after the activation (training only) */
+  int32_t group_mean;  /* HeteroConv aggr: 0 = sum, 1 = mean over the convs reaching a node type */
+  int32_t out_dim[HMP_MAX_NODE_TYPES]; /* output width per node type (0 = type receives nothing) */
+  hmp_conv_spec convs[HMP_MAX_CONVS];
+} hmp_layer_spec;
+
+typedef struct hmp_net_spec {
+  int32_t n_node_types, n_edge_types, n_layers;
+  int32_t in_dim[HMP_MAX_NODE_TYPES];
+  int32_t edge_src[HMP_MAX_EDGE_TYPES], edge_dst[HMP_MAX_EDGE_TYPES];
+  int32_t readout_type;    /* node type whose final state is the output */
+  int32_t pool_edge_type;  /* -1, or LeafPool edge type: output = segment mean over it, first n_out rows */
+  int64_t n_params;        /* total floats in the flat parameter buffer */
+  int64_t n_active_params; /* parameters [0, n_active) receive gradients; the tail is dead weights */
+  hmp_layer_spec layers[HMP_MAX_LAYERS];
+} hmp_net_spec;
+
+typedef struct hmp_batch {
+  int32_t n_nodes[HMP_MAX_NODE_TYPES];
+  const float* d_x[HMP_MAX_NODE_TYPES];   /* [n_nodes, in_dim] */
+  int32_t ldx[HMP_MAX_NODE_TYPES];
+  int64_t n_edges[HMP_MAX_EDGE_TYPES];
+  const int64_t* d_edge_index[HMP_MAX_EDGE_TYPES]; /* [2][E] int64 */
+  const float* d_edge_attr[HMP_MAX_EDGE_TYPES];    /* [E, edge_dim] or NULL */
+  int32_t n_out;             /* rows of the output (== n_nodes[readout] unless pooled) */
+  const int64_t* d_labels;   /* [n_out] int64, or NULL (forward only) */
+} hmp_batch;
+
+typedef struct hmp_train_args {
+  float lr, beta1, beta2, eps, weight_decay;
+  int64_t ignored_label;
+  uint64_t seed;
+  int32_t training;          /* dropout on */
+} hmp_train_args;
+
+typedef struct hmp_net hmp_net; /* opaque */
+
+int hmp_net_create(const hmp_net_spec* spec, hmp_net** out);
+void hmp_net_destroy(hmp_net* net);
+/* device bytes the executor needs for batches up to these capacities */
+size_t hmp_net_workspace_bytes(const hmp_net* net, const int32_t* cap_nodes, const int64_t* cap_edges);
+int hmp_net_bind_workspace(hmp_net* net, void* d_workspace, size_t bytes, const int32_t* cap_nodes, const int64_t* cap_edges);
+
+/* forward: builds the plan for `batch`, runs every layer; *d_out -> [n_out, out_dim] inside the
+ * workspace (ld = *ld_out).  rng_step selects the dropout stream of this call. */
+int hmp_net_forward(hmp_net* net, const hmp_batch* batch, const float* d_params, int32_t training, uint64_t seed,
+                    uint32_t rng_step, const float** d_out, int32_t* ld_out, void* stream);
+/* backward of the last forward: d_gout [n_out, ld_gout] -> flat gradient d_grads[0 : n_active_params)
+ * (overwritten, not accumulated).  d_gx[t] (may be NULL) receives d loss / d x[t], ld = ldx[t]. */
+int hmp_net_backward(hmp_net* net, const float* d_gout, int32_t ld_gout, const float* d_params, float* d_grads,
+                     float* const* d_gx, void* stream);
+
+/* fused training step, phase A: plan + forward + masked CE + backward.  Leaves the SUM-loss gradient in
+ * d_grads[0 : n_active) and {loss_sum, count} in d_grads[n_active], d_grads[n_active+1] so that ONE
+ * all-reduce(sum) over n_active+2 floats averages count-weighted across ranks.  Phase B: Adam on
+ * [0, n_active) with grad scale 1/count read from that tail.  The step counter lives on the device so
+ * both phases can be replayed from a captured hipGraph. */
+int hmp_net_step_fwd_bwd(hmp_net* net, const hmp_batch* batch, const float* d_params, float* d_grads,
+                         const hmp_train_args* args, void* stream);
+int hmp_net_step_adam(hmp_net* net, float* d_params, const float* d_grads, float* d_m, float* d_v,
+                      const hmp_train_args* args, void* stream);
+/* host copy of {step counter, status bits}; synchronises the stream */
+int hmp_net_read_state(hmp_net* net, int32_t* step, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 7. hipGraph capture of a launch sequence (the step is ~20 short kernels: launch-bound).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hmp_graph hmp_graph;
+int hmp_graph_begin(void* stream);                   /* stream must not be the null stream */
+int hmp_graph_end(void* stream, hmp_graph** out);
+int hmp_graph_launch(hmp_graph* g, void* stream);
+void hmp_graph_destroy(hmp_graph* g);
+
+/* HIP event timing on the caller's stream (bench.py roofline leg) */
+typedef struct hmp_timer hmp_timer;
+int hmp_timer_create(hmp_timer** out);
+int hmp_timer_start(hmp_timer* t, void* stream);
+int hmp_timer_stop(hmp_timer* t, void* stream);
+int hmp_timer_elapsed_ms(hmp_timer* t, float* ms); /* synchronises on the stop event */
+void hmp_timer_destroy(hmp_timer* t);
+/* per-kernel-class device time accumulated by the executor when profiling is on (HIP events around
+ * every launch of that class on the executor's stream).  classes: 0 plan, 1 pack, 2 gemm_fwd,
+ * 3 aggregate_fwd, 4 loss, 5 aggregate_bwd, 6 gemm_bwd, 7 grad_reduce, 8 adam, 9 gat_fwd, 10 gat_bwd */
+#define HMP_N_KCLASS 12
+int hmp_net_profile(hmp_net* net, int32_t enable);
+int hmp_net_profile_read(hmp_net* net, float* ms_sum /*[HMP_N_KCLASS]*/, int32_t* launches /*[HMP_N_KCLASS]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRA_MP_H */

@@ -1,0 +1,278 @@
+"""ORACLE (test infrastructure, not product code) -- the reference's model compositions on top of
+:mod:`oracle.pyg_ref`.  Parity status: see the header of ``pyg_ref.py`` ("parity unpinned").
+
+Follows, without importing it (it needs torch_geometric):
+
+* ``src/hydra_gnn/models/heterogeneous_network.py:40-136``  -> :class:`HeterogeneousNetwork`
+* ``src/hydra_gnn/models/heterogeneous_neural_tree_network.py:40-205`` -> :class:`HeterogeneousNeuralTreeNetwork`
+* ``src/hydra_gnn/models/homogeneous_network.py:44-147`` (SAGE / GAT branches) -> :class:`HomogeneousNetwork`
+* ``src/hydra_gnn/models/utils.py:9-140`` (layer builders)
+
+state_dict keys equal the reference's PyG <= 2.3 keys, so a state_dict moves
+between these oracles and ``hydra_gnn_amd.models`` unchanged.
+
+``dropout_fn(x, p, training, tag)`` lets a test inject the exact keep-masks the HIP engine draws
+(tags: ``"L{layer}.{node_type}"`` for feature dropout, ``"L{layer}.{edge_type}.alpha"`` for
+attention dropout).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pyg_ref import (
+    GATConv,
+    HeteroConv,
+    LeafPool,
+    Linear,
+    SAGEConv,
+    cross_entropy_loss,
+    default_dropout,
+)
+
+EDGE_TYPES = [
+    ("objects", "objects_to_objects", "objects"),
+    ("rooms", "rooms_to_rooms", "rooms"),
+    ("objects", "objects_to_rooms", "rooms"),
+    ("rooms", "rooms_to_objects", "objects"),
+]
+HTREE_NODE_TYPES = ["object", "room", "object-room", "room-room"]
+HTREE_EDGE_TYPES = [
+    ("object", "o_to_or", "object-room"),
+    ("object-room", "or_to_o", "object"),
+    ("room", "r_to_or", "object-room"),
+    ("object-room", "or_to_r", "room"),
+    ("room", "r_to_rr", "room-room"),
+    ("room-room", "rr_to_r", "room"),
+    ("object-room", "or_ro_rr", "room-room"),
+    ("room-room", "rr_ro_or", "object-room"),
+    ("object-room", "or_to_or", "object-room"),
+    ("room-room", "rr_to_rr", "room-room"),
+]
+HTREE_INIT_EDGE_TYPES = [
+    ("object_virtual", "ov_to_or", "object-room"),
+    ("room_virtual", "rv_to_or", "object-room"),
+    ("room_virtual", "rv_to_rr", "room-room"),
+]
+
+
+def _sage_hetero_layers(edge_types, in_dims, hidden, out_dims, num_layers):
+    """models/utils.py:90-100 applied as heterogeneous_network.py:80-97."""
+    node_types = list(out_dims.keys())
+    dims = [dict(in_dims)] + [{t: hidden for t in node_types} for _ in range(num_layers - 1)] + [dict(out_dims)]
+    layers = nn.ModuleList()
+    for l in range(num_layers):
+        layers.append(
+            HeteroConv({(s, r, t): SAGEConv((dims[l][s], dims[l][t]), dims[l + 1][t]) for s, r, t in edge_types}, aggr="sum")
+        )
+    return layers
+
+
+def _gat_hetero_layers(edge_types, in_dims, out_dims, hidden_dims, heads, concats, dropout, edge_dim, fill_value, dropout_fn):
+    """models/utils.py:103-140 (per edge type a chain built by build_GAT_conv_layers :31-87)."""
+    L = len(heads)
+    per_type = {}
+    for s, r, t in edge_types:
+        widths = list(hidden_dims) + [out_dims[t]]
+        assert len(widths) == L and len(concats) == L
+        chain = []
+        fin = (in_dims[s], in_dims[t])
+        for l in range(L):
+            chain.append(
+                GATConv(
+                    fin, widths[l], heads=heads[l], concat=concats[l], dropout=dropout,
+                    add_self_loops=(s == t), edge_dim=edge_dim, fill_value=fill_value,
+                    dropout_fn=dropout_fn, tag=f"L{l}.{'__'.join((s, r, t))}",
+                )
+            )
+            # NB the reference feeds an int here (models/utils.py:60-86): later layers share
+            # lin_src/lin_dst (one Linear) even for bipartite edge types.
+            fin = widths[l] * heads[l] if concats[l] else widths[l]
+        per_type[(s, r, t)] = chain
+    return nn.ModuleList(HeteroConv({et: per_type[et][l] for et in per_type}, aggr="sum") for l in range(L))
+
+
+class _HeteroBase(nn.Module):
+    def _run_layers(self, data, x_dict, edge_index_dict):
+        for l in range(self.num_layers):
+            if self.conv_block == "GAT_edge":
+                x_dict = self.convs[l](x_dict, edge_index_dict, data.edge_attr_dict)
+            else:
+                x_dict = self.convs[l](x_dict, edge_index_dict)
+            if l != self.num_layers - 1:
+                x_dict = self._act_drop(x_dict, l)
+        return x_dict
+
+    def _act_drop(self, x_dict, l):
+        act = F.relu if self.conv_block[:3] != "GAT" else F.elu
+        return {k: self.dropout_fn(act(v), self.dropout, self.training, f"L{l}.{k}") for k, v in x_dict.items()}
+
+    def loss(self, pred, label, mask=None):
+        return cross_entropy_loss(pred, label, mask)
+
+
+class HeterogeneousNetwork(_HeteroBase):
+    def __init__(self, input_dim_dict, output_dim=None, output_dim_dict=None, conv_block="GraphSAGE",
+                 hidden_dim=None, num_layers=None, GAT_hidden_dims=None, GAT_heads=None, GAT_concats=None,
+                 dropout=0.25, dropout_fn=default_dropout, **kwargs):
+        super().__init__()
+        assert conv_block in ["GraphSAGE", "GAT", "GAT_edge"]
+        self.conv_block, self.dropout, self.dropout_fn = conv_block, dropout, dropout_fn
+        if output_dim is not None:
+            assert output_dim_dict is None
+            self.classification_task = "room"
+            output_dim_dict = {"rooms": output_dim, "objects": output_dim}
+        else:
+            assert output_dim_dict is not None
+            self.classification_task = "all"
+        if conv_block == "GraphSAGE":
+            self.num_layers = num_layers
+            self.convs = _sage_hetero_layers(EDGE_TYPES, input_dim_dict, hidden_dim, output_dim_dict, num_layers)
+        else:
+            self.num_layers = len(GAT_heads)
+            edge = conv_block == "GAT_edge"
+            self.convs = _gat_hetero_layers(
+                EDGE_TYPES, input_dim_dict, output_dim_dict, GAT_hidden_dims, GAT_heads, GAT_concats, dropout,
+                edge_dim=3 if edge else None,
+                fill_value=torch.zeros(3, dtype=torch.float64) if edge else "mean",
+                dropout_fn=dropout_fn,
+            )
+
+    def forward(self, data):
+        x_dict = self._run_layers(data, data.x_dict, data.edge_index_dict)
+        if self.classification_task == "room":
+            return x_dict["rooms"]
+        x_dict = self._act_drop(x_dict, self.num_layers - 1)
+        return x_dict["rooms"], x_dict["objects"]
+
+
+class HeterogeneousNeuralTreeNetwork(_HeteroBase):
+    def __init__(self, input_dim_dict, output_dim=None, output_dim_dict=None, conv_block="GraphSAGE",
+                 disable_initialization=False, hidden_dim=None, num_layers=None, GAT_hidden_dims=None,
+                 GAT_heads=None, GAT_concats=None, dropout=0.25, dropout_fn=default_dropout, **kwargs):
+        super().__init__()
+        assert conv_block in ["GraphSAGE", "GAT", "GAT_edge"]
+        self.conv_block, self.dropout, self.dropout_fn = conv_block, dropout, dropout_fn
+        if output_dim is not None:
+            assert output_dim_dict is None
+            self.classification_task = "room"
+            output_dim_dict = {t: output_dim for t in HTREE_NODE_TYPES}
+        else:
+            assert output_dim_dict is not None
+            self.classification_task = "all"
+        assert input_dim_dict["object"] == input_dim_dict["object_virtual"]
+        assert input_dim_dict["room"] == input_dim_dict["room_virtual"]
+        assert input_dim_dict["object-room"] == input_dim_dict["room-room"]
+        if disable_initialization:
+            self.pre_mp = None
+        else:
+            self.pre_mp = HeteroConv(
+                {
+                    (s, r, t): GATConv((input_dim_dict[s], input_dim_dict[t]), input_dim_dict[t], heads=1,
+                                       concat=False, dropout=0.0, add_self_loops=False)
+                    for s, r, t in HTREE_INIT_EDGE_TYPES
+                },
+                aggr="mean",
+            )
+        mp_in = {t: input_dim_dict[t] for t in HTREE_NODE_TYPES}
+        if conv_block == "GraphSAGE":
+            self.num_layers = num_layers
+            self.convs = _sage_hetero_layers(HTREE_EDGE_TYPES, mp_in, hidden_dim, output_dim_dict, num_layers)
+        else:
+            self.num_layers = len(GAT_heads)
+            edge = conv_block == "GAT_edge"
+            self.convs = _gat_hetero_layers(
+                HTREE_EDGE_TYPES, mp_in, output_dim_dict, GAT_hidden_dims, GAT_heads, GAT_concats, dropout,
+                edge_dim=3 if edge else None,
+                fill_value=torch.zeros(3, dtype=torch.float64) if edge else "mean",
+                dropout_fn=dropout_fn,
+            )
+        self.post_mp = LeafPool()
+
+    def forward(self, data):
+        x_dict, edge_index_dict = data.x_dict, data.edge_index_dict
+        if self.pre_mp is not None:
+            x_dict.update(self.pre_mp(x_dict, edge_index_dict))
+        x_dict = self._run_layers(data, x_dict, edge_index_dict)
+        if self.classification_task == "room":
+            return self.post_mp(x_dict["room"], edge_index_dict["room", "r_to_rv", "room_virtual"])[
+                0 : data["room_virtual"].num_nodes
+            ]
+        x_dict = self._act_drop(x_dict, self.num_layers - 1)
+        x_room = self.post_mp(x_dict["room"], edge_index_dict["room", "r_to_rv", "room_virtual"])[
+            0 : data["room_virtual"].num_nodes
+        ]
+        x_object = self.post_mp(x_dict["object"], edge_index_dict["object", "o_to_ov", "object_virtual"])[
+            0 : data["object_virtual"].num_nodes
+        ]
+        return x_room, x_object
+
+
+class HomogeneousNetwork(nn.Module):
+    """SAGE / GAT / GAT_edge branches of homogeneous_network.py (GCN/GIN are out of scope)."""
+
+    def __init__(self, input_dim, output_dim=None, output_dim_dict=None, conv_block="GraphSAGE", hidden_dim=None,
+                 num_layers=None, GAT_hidden_dims=None, GAT_heads=None, GAT_concats=None, dropout=0.25,
+                 dropout_fn=default_dropout, **kwargs):
+        super().__init__()
+        assert conv_block in ["GraphSAGE", "GAT", "GAT_edge"]
+        self.conv_block, self.dropout, self.dropout_fn = conv_block, dropout, dropout_fn
+        gat = conv_block[:3] == "GAT"
+        if output_dim is not None:
+            assert output_dim_dict is None
+            self.classification_task = "room"
+            mp_out = output_dim
+            widths = (list(GAT_hidden_dims) + [output_dim]) if gat else None
+        else:
+            assert output_dim_dict is not None
+            self.classification_task = "all"
+            mp_out = hidden_dim
+            widths = list(GAT_hidden_dims) if gat else None
+        self.convs = nn.ModuleList()
+        if gat:
+            self.num_layers = len(GAT_heads)
+            fin = input_dim
+            for l in range(self.num_layers):
+                self.convs.append(
+                    GATConv(fin, widths[l], heads=GAT_heads[l], concat=GAT_concats[l], dropout=dropout,
+                            add_self_loops=True, edge_dim=3 if conv_block == "GAT_edge" else None,
+                            fill_value=torch.zeros(3, dtype=torch.float64) if conv_block == "GAT_edge" else "mean",
+                            dropout_fn=dropout_fn, tag=f"L{l}.homo")
+                )
+                fin = widths[l] * GAT_heads[l] if GAT_concats[l] else widths[l]
+            final_hidden = fin
+        else:
+            self.num_layers = num_layers
+            dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [mp_out]
+            for l in range(num_layers):
+                self.convs.append(SAGEConv(dims[l], dims[l + 1]))
+            final_hidden = hidden_dim
+        if self.classification_task == "all":
+            n_room = output_dim_dict["rooms"] if "rooms" in output_dim_dict else output_dim_dict["room"]
+            n_obj = output_dim_dict["objects"] if "objects" in output_dim_dict else output_dim_dict["object"]
+            self.post_mp_room = nn.Linear(final_hidden, n_room)
+            self.post_mp_object = nn.Linear(final_hidden, n_obj)
+
+    def _act_drop(self, x, l):
+        act = F.relu if self.conv_block[:3] != "GAT" else F.elu
+        return self.dropout_fn(act(x), self.dropout, self.training, f"L{l}.homo")
+
+    def forward(self, data):
+        x, edge_index, room_mask = data.x, data.edge_index, data.room_mask
+        for l in range(self.num_layers):
+            if self.conv_block == "GAT_edge":
+                x = self.convs[l](x, edge_index, data.edge_attr)
+            else:
+                x = self.convs[l](x, edge_index)
+            if l != self.num_layers - 1:
+                x = self._act_drop(x, l)
+        if self.classification_task == "room":
+            return x[room_mask, :]
+        x = self._act_drop(x, self.num_layers - 1)
+        return self.post_mp_room(x[room_mask, :]), self.post_mp_object(x[~room_mask, :])
+
+    def loss(self, pred, label, mask=None):
+        return cross_entropy_loss(pred, label, mask)

@@ -1,0 +1,215 @@
+"""GPU parity of the individual C-ABI kernels against the oracle (CPU restatement of the PyG ops).
+
+Tolerances: indices bit-exact; fp32 activations within atol 1e-5 + rtol 1e-5 of the oracle evaluated in
+float64 (north_star: "bit-exact on indexing and within 1e-5 fp32 on activations/logits").
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hydra_gnn_amd import _lib  # noqa: E402
+from oracle import pyg_ref  # noqa: E402
+
+ATOL, RTOL = 1e-5, 1e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def sp():
+    return _lib.stream_ptr()
+
+
+def build_plan(ei: torch.Tensor, n_src: int, n_dst: int):
+    lib = _lib.require_device()
+    E = ei.size(1)
+    d = ei.device
+    t = {
+        "rowptr": torch.full((n_dst + 1,), -7, dtype=torch.int32, device=d),
+        "col": torch.full((max(E, 1),), -7, dtype=torch.int32, device=d),
+        "eid": torch.full((max(E, 1),), -7, dtype=torch.int32, device=d),
+        "t_rowptr": torch.full((n_src + 1,), -7, dtype=torch.int32, device=d),
+        "t_col": torch.full((max(E, 1),), -7, dtype=torch.int32, device=d),
+        "t_pos": torch.full((max(E, 1),), -7, dtype=torch.int32, device=d),
+    }
+    plan = _lib.Plan(n_src, n_dst, E, t["rowptr"].data_ptr(), t["col"].data_ptr(), t["eid"].data_ptr(),
+                     t["t_rowptr"].data_ptr(), t["t_col"].data_ptr(), t["t_pos"].data_ptr())
+    scratch = torch.empty(max(int(lib.hmp_plan_scratch_bytes(E, n_src, n_dst)), 16), dtype=torch.uint8, device=d)
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+    _lib.check(lib.hmp_plan_build(ei.data_ptr() if E > 0 else None, plan, scratch.data_ptr(), status.data_ptr(), sp()))
+    torch.cuda.synchronize()
+    t["status"] = int(status.item())
+    t["plan"] = plan
+    return t
+
+
+def rand_edges(rng, E, n_src, n_dst):
+    return torch.from_numpy(np.stack([rng.integers(0, max(n_src, 1), E), rng.integers(0, max(n_dst, 1), E)]).astype(np.int64))
+
+
+@pytest.mark.parametrize("E,n_src,n_dst", [(0, 3, 4), (1, 1, 1), (17, 5, 3), (482, 62, 62), (20000, 700, 90), (5000, 1, 4000), (3000, 2000, 1)])
+def test_plan_bit_exact(E, n_src, n_dst):
+    rng = np.random.default_rng(E + n_src)
+    ei = rand_edges(rng, E, n_src, n_dst)
+    p = build_plan(ei.to(dev()), n_src, n_dst)
+    assert p["status"] == 0
+    src, dst = ei[0], ei[1]
+    # oracle: stable sort by destination / by source
+    order = torch.sort(dst, stable=True).indices
+    rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
+    t_order = torch.sort(src, stable=True).indices
+    t_rowptr = torch.zeros(n_src + 1, dtype=torch.int64)
+    t_rowptr[1:] = torch.cumsum(torch.bincount(src, minlength=n_src), 0)
+    assert torch.equal(p["rowptr"].cpu().long(), rowptr)
+    assert torch.equal(p["t_rowptr"].cpu().long(), t_rowptr)
+    if E:
+        assert torch.equal(p["eid"].cpu().long()[:E], order)
+        assert torch.equal(p["col"].cpu().long()[:E], src[order])
+        assert torch.equal(p["t_col"].cpu().long()[:E], dst[t_order])
+        pos_of = torch.empty(E, dtype=torch.int64)
+        pos_of[order] = torch.arange(E)
+        assert torch.equal(p["t_pos"].cpu().long()[:E], pos_of[t_order])
+
+
+def test_plan_flags_out_of_range_edges():
+    ei = torch.tensor([[0, 1, 9, 1], [0, 1, 1, -1]], dtype=torch.int64)
+    p = build_plan(ei.to(dev()), 3, 2)
+    assert p["status"] & 1
+    assert p["rowptr"].cpu().tolist() == [0, 1, 2]  # the two bad edges are dropped
+
+
+def test_plan_is_deterministic():
+    rng = np.random.default_rng(5)
+    ei = rand_edges(rng, 30000, 300, 200).to(dev())
+    a = build_plan(ei, 300, 200)
+    for _ in range(3):
+        b = build_plan(ei, 300, 200)
+        for k in ("rowptr", "col", "eid", "t_rowptr", "t_col", "t_pos"):
+            assert torch.equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("F,ld_pad", [(6, 0), (26, 2), (64, 0), (128, 0), (306, 0), (308, 4), (512, 0), (1100, 0)])
+def test_segment_mean_fwd_bwd(F, ld_pad):
+    lib = _lib.require_device()
+    rng = np.random.default_rng(F)
+    n_src, n_dst, E = 150, 70, 900
+    ei = rand_edges(rng, E, n_src, n_dst)
+    ei[1, ei[1] == 3] = 4  # make row 3 empty
+    p = build_plan(ei.to(dev()), n_src, n_dst)
+    ld = F + ld_pad
+    x_full = torch.from_numpy(rng.normal(size=(n_src, ld)).astype(np.float32))
+    xg = x_full.to(dev())
+    out = torch.full((n_dst, ld), 7.0, dtype=torch.float32, device=dev())
+    _lib.check(lib.hmp_segment_mean_fwd(xg.data_ptr(), ld, F, p["plan"], out.data_ptr(), ld, sp()))
+    x64 = x_full[:, :F].double().requires_grad_(True)
+    ref = pyg_ref.scatter_mean(x64.index_select(0, ei[0]), ei[1], n_dst)
+    torch.testing.assert_close(out[:, :F].cpu().double(), ref.detach(), atol=ATOL, rtol=RTOL)
+    assert torch.all(out[3, :F] == 0)
+    if ld_pad:
+        assert torch.all(out[:, F:] == 7.0)  # padding untouched
+    g_full = torch.from_numpy(rng.normal(size=(n_dst, ld)).astype(np.float32))
+    gx = torch.full((n_src, ld), 7.0, dtype=torch.float32, device=dev())
+    _lib.check(lib.hmp_segment_mean_bwd(g_full.to(dev()).data_ptr(), ld, F, p["plan"], gx.data_ptr(), ld, sp()))
+    ref.backward(g_full[:, :F].double())
+    torch.testing.assert_close(gx[:, :F].cpu().double(), x64.grad, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize(
+    "M,N,K,ta,tb",
+    [(1, 1, 1, 0, 1), (37, 29, 6, 0, 1), (235, 128, 6, 0, 1), (2831, 192, 306, 0, 1), (2831, 306, 192, 0, 0),
+     (192, 307, 2831, 1, 0), (64, 64, 64, 1, 1), (5000, 512, 256, 0, 1), (33, 65, 31, 0, 0), (40000, 256, 256, 0, 1)],
+)
+def test_gemm_f32(M, N, K, ta, tb):
+    lib = _lib.require_device()
+    rng = np.random.default_rng(M * 7 + N)
+    A = torch.from_numpy(rng.uniform(-1, 1, size=(M, K)).astype(np.float32))
+    B = torch.from_numpy(rng.uniform(-1, 1, size=(K, N)).astype(np.float32))
+    a_mem = (A.t() if ta else A).contiguous().to(dev())
+    b_mem = (B.t() if tb else B).contiguous().to(dev())
+    Cd = torch.full((M, N + 3), 5.0, dtype=torch.float32, device=dev())
+    _lib.check(lib.hmp_gemm_f32(a_mem.data_ptr(), a_mem.stride(0), ta, b_mem.data_ptr(), b_mem.stride(0), tb, Cd.data_ptr(),
+                                N + 3, M, N, K, sp()))
+    ref = A.double() @ B.double()
+    # fp32 FMA chain of length K with |a*b| <= 1: error bound ~ K * 2^-24 * sqrt-ish; use the north_star tolerance
+    # scaled by the magnitude of the accumulated sum
+    tol = ATOL * max(1.0, float(ref.abs().max()))
+    assert float((Cd[:, :N].cpu().double() - ref).abs().max()) <= tol
+    assert torch.all(Cd[:, N:] == 5.0)
+
+
+def test_gemm_asymmetric_operands_catch_transposition():
+    """A = I, B asymmetric: a swapped accumulator row/col map would give C = B^T (guide section 3)."""
+    lib = _lib.require_device()
+    n = 96
+    A = torch.eye(n)
+    B = torch.arange(n * n, dtype=torch.float32).view(n, n)
+    Cd = torch.zeros(n, n, device=dev())
+    _lib.check(lib.hmp_gemm_f32(A.to(dev()).data_ptr(), n, 0, B.to(dev()).data_ptr(), n, 0, Cd.data_ptr(), n, n, n, n, sp()))
+    assert torch.equal(Cd.cpu(), B)
+
+
+@pytest.mark.parametrize("n,c", [(1, 26), (235, 26), (5000, 15), (7, 3)])
+def test_masked_ce(n, c):
+    lib = _lib.require_device()
+    rng = np.random.default_rng(n)
+    logits = torch.from_numpy(rng.normal(0, 3, size=(n, c)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, c, size=n).astype(np.int64))
+    ignored = c - 1
+    ld = ((c + 3) // 4) * 4
+    lg = torch.zeros(n, ld, device=dev())
+    lg[:, :c] = logits.to(dev())
+    grad = torch.full((n, ld), 9.0, device=dev())
+    out2 = torch.zeros(2, device=dev())
+    _lib.check(lib.hmp_masked_ce(lg.data_ptr(), ld, n, c, labels.to(dev()).data_ptr(), ignored, grad.data_ptr(), ld, out2.data_ptr(), sp()))
+    mask = labels != ignored
+    l64 = logits.double().requires_grad_(True)
+    if int(mask.sum()) == 0:
+        assert out2.cpu().tolist() == [0.0, 0.0]
+        return
+    ref = torch.nn.functional.cross_entropy(l64[mask], labels[mask], reduction="sum")
+    ref.backward()
+    got = out2.cpu().double()
+    assert int(got[1]) == int(mask.sum())
+    torch.testing.assert_close(got[0], ref.detach(), atol=1e-5 * max(1, int(mask.sum())), rtol=1e-5)
+    torch.testing.assert_close(grad[:, :c].cpu().double(), l64.grad, atol=ATOL, rtol=RTOL)
+    assert torch.all(grad[:, c:] == 0)
+
+
+def test_adam_matches_torch():
+    lib = _lib.require_device()
+    torch.manual_seed(0)
+    n = 10007
+    p0 = torch.randn(n)
+    ref_p = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=0.002, weight_decay=0.001)
+    p = p0.clone().to(dev())
+    m = torch.zeros(n, device=dev())
+    v = torch.zeros(n, device=dev())
+    for step in range(1, 6):
+        g = torch.randn(n)
+        ref_p.grad = g.double()
+        opt.step()
+        _lib.check(lib.hmp_adam_flat(p.data_ptr(), g.to(dev()).data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.002, 0.9, 0.999,
+                                     1e-8, 0.001, step, None, sp()))
+    torch.testing.assert_close(p.cpu().double(), ref_p.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_dropout_mask_rate_and_determinism():
+    lib = _lib.require_device()
+    n, F = 4000, 64
+    a = torch.zeros(n * F, dtype=torch.uint8, device=dev())
+    b = torch.zeros(n * F, dtype=torch.uint8, device=dev())
+    c = torch.zeros(n * F, dtype=torch.uint8, device=dev())
+    _lib.check(lib.hmp_dropout_mask(1234, 1, 3, 0.25, n, F, a.data_ptr(), sp()))
+    _lib.check(lib.hmp_dropout_mask(1234, 1, 3, 0.25, n, F, b.data_ptr(), sp()))
+    _lib.check(lib.hmp_dropout_mask(1234, 2, 3, 0.25, n, F, c.data_ptr(), sp()))
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c)
+    keep = float(a.float().mean())
+    assert abs(keep - 0.75) < 0.005
