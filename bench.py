@@ -243,7 +243,8 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import models as omodels
 
-        cores = os.cpu_count() or 1
+        # the GPU box gives one-GPU jobs a 16-CPU share; more intra-op threads than that only oversubscribes
+        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         torch.set_num_threads(cores)
         torch.manual_seed(1234)
         ora = omodels.HeterogeneousNetwork(**model_kw)

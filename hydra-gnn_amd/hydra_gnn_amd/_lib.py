@@ -141,6 +141,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64: it must be in the process BEFORE our library is
+    # dlopen'ed, so that both resolve to ONE HIP runtime (device pointers and streams are shared between them);
+    # loading libhydra_mp.so first would pull /opt/rocm's runtime in and leave torch on a second, blind copy.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise HydraMPError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

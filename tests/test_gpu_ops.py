@@ -115,7 +115,8 @@ def test_segment_mean_fwd_bwd(F, ld_pad):
         assert torch.all(out[:, F:] == 7.0)  # padding untouched
     g_full = torch.from_numpy(rng.normal(size=(n_dst, ld)).astype(np.float32))
     gx = torch.full((n_src, ld), 7.0, dtype=torch.float32, device=dev())
-    _lib.check(lib.hmp_segment_mean_bwd(g_full.to(dev()).data_ptr(), ld, F, p["plan"], gx.data_ptr(), ld, sp()))
+    g_dev = g_full.to(dev())
+    _lib.check(lib.hmp_segment_mean_bwd(g_dev.data_ptr(), ld, F, p["plan"], gx.data_ptr(), ld, sp()))
     ref.backward(g_full[:, :F].double())
     torch.testing.assert_close(gx[:, :F].cpu().double(), x64.grad, atol=ATOL, rtol=RTOL)
 
@@ -150,8 +151,13 @@ def test_gemm_asymmetric_operands_catch_transposition():
     A = torch.eye(n)
     B = torch.arange(n * n, dtype=torch.float32).view(n, n)
     Cd = torch.zeros(n, n, device=dev())
-    _lib.check(lib.hmp_gemm_f32(A.to(dev()).data_ptr(), n, 0, B.to(dev()).data_ptr(), n, 0, Cd.data_ptr(), n, n, n, n, sp()))
+    Ad, Bd = A.to(dev()), B.to(dev())  # keep the device tensors alive while the kernel runs
+    _lib.check(lib.hmp_gemm_f32(Ad.data_ptr(), n, 0, Bd.data_ptr(), n, 0, Cd.data_ptr(), n, n, n, n, sp()))
     assert torch.equal(Cd.cpu(), B)
+    _lib.check(lib.hmp_gemm_f32(Bd.data_ptr(), n, 0, Ad.data_ptr(), n, 1, Cd.data_ptr(), n, n, n, n, sp()))
+    assert torch.equal(Cd.cpu(), B)
+    _lib.check(lib.hmp_gemm_f32(Bd.data_ptr(), n, 1, Ad.data_ptr(), n, 0, Cd.data_ptr(), n, n, n, n, sp()))
+    assert torch.equal(Cd.cpu(), B.t())
 
 
 @pytest.mark.parametrize("n,c", [(1, 26), (235, 26), (5000, 15), (7, 3)])
@@ -166,7 +172,8 @@ def test_masked_ce(n, c):
     lg[:, :c] = logits.to(dev())
     grad = torch.full((n, ld), 9.0, device=dev())
     out2 = torch.zeros(2, device=dev())
-    _lib.check(lib.hmp_masked_ce(lg.data_ptr(), ld, n, c, labels.to(dev()).data_ptr(), ignored, grad.data_ptr(), ld, out2.data_ptr(), sp()))
+    lab_dev = labels.to(dev())
+    _lib.check(lib.hmp_masked_ce(lg.data_ptr(), ld, n, c, lab_dev.data_ptr(), ignored, grad.data_ptr(), ld, out2.data_ptr(), sp()))
     mask = labels != ignored
     l64 = logits.double().requires_grad_(True)
     if int(mask.sum()) == 0:
@@ -195,8 +202,10 @@ def test_adam_matches_torch():
         g = torch.randn(n)
         ref_p.grad = g.double()
         opt.step()
-        _lib.check(lib.hmp_adam_flat(p.data_ptr(), g.to(dev()).data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.002, 0.9, 0.999,
+        g_dev = g.to(dev())
+        _lib.check(lib.hmp_adam_flat(p.data_ptr(), g_dev.data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.002, 0.9, 0.999,
                                      1e-8, 0.001, step, None, sp()))
+        torch.cuda.synchronize()
     torch.testing.assert_close(p.cpu().double(), ref_p.detach(), atol=1e-6, rtol=1e-5)
 
 
