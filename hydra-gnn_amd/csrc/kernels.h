@@ -121,29 +121,131 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st);
 // ---------------------------------------------------------------------------------------------
 // parameter packing / gradient un-packing (tables live in device memory, built at bind time)
 // ---------------------------------------------------------------------------------------------
+// kinds of packed rows
+//  PACK_SUM     row r            = sum_q P[src[q]][r, :]                       (SAGE weights, root sums, bias sums)
+//  PACK_HEADS   row h*Cp + c     = P[src[0]][h*C + c, :] (c < C), else 0       (GAT lin_src with heads padded to 4)
+//  PACK_ATTDOT  row h            = sum_c P[att][h*C + c] * P[src[0]][h*C + c, :]   (V^T = fold of att into lin: a = x * V)
+//  PACK_ATTDOT_T element (d, h)  = sum_c P[att][h*C + c] * P[src[0]][(h*C + c), d] (V_edge [edge_dim][H])
+enum { PACK_SUM = 0, PACK_HEADS = 1, PACK_ATTDOT = 2, PACK_ATTDOT_T = 3 };
 struct PackSeg {
   int64_t dst;      // float offset into the packed buffer
   int rows, rows_pad, cols, ld_dst;
   int ld_src;       // == cols (parameters are dense)
   int nsrc;
+  int kind, H, C, Cp;
+  int64_t att;      // PACK_ATTDOT*: float offset of the attention vector [H*C]
   int64_t src[AGG_MAX_IN];  // float offsets into the flat parameter buffer (summed)
 };
 int pack_launch(const PackSeg* d_segs, int n_segs, int64_t total_rows, const int64_t* d_row_start, const float* d_params,
                 float* d_packed, hipStream_t st);
 
+// A parameter gradient element (r, c) is the sum of up to 3 terms read from split-K slabs S (summed over slabs):
+//  GT_COPY       S[(r/C*Cp + r%C) * ld + c]                         (rows of the stacked operand; C = Cp: identity)
+//  GT_ATT_OUTER  P[att + r] * S[(r/C) * ld + c]                     (d lin from a = x * fold(att, lin))
+//  GT_ATT_DOT    sum_f S[(r/C) * ld + f] * P[w + r * ldw + f]       (d att; parameter element r = h*C + c, cols = 1)
+//  GT_ATT_OUTER_T  P[att + r] * S[c * ld + r/C]                     (d lin_edge from V_edge [D][H])
+//  GT_ATT_DOT_T    sum_d S[d * ld + r/C] * P[w + r * ldw + d]       (d att_edge)
+enum { GT_COPY = 0, GT_ATT_OUTER = 1, GT_ATT_DOT = 2, GT_ATT_OUTER_T = 3, GT_ATT_DOT_T = 4 };
+struct GradTerm {
+  int kind;
+  int slab_id;      // index into the per-call n_slabs / slab_stride arrays
+  int64_t src;      // float offset of the term's origin inside slab 0
+  int ld;
+  int C, Cp;
+  int inner;        // GT_ATT_DOT*: length of the dot product
+  int64_t att, w;   // parameter offsets
+  int ldw;
+  float scale;
+};
 struct GradSeg {
   int64_t dst;       // float offset into the flat gradient buffer
-  int rows, cols;    // parameter shape (bias: cols = 1)
-  int64_t src;       // float offset of element (0,0) inside slab 0 of the packed-gradient buffer
-  int ld_src;
-  int slab_id;       // index into the per-call n_slabs / slab_stride arrays
+  int rows, cols;    // parameter shape (vectors: cols = 1)
+  int n_terms;
+  GradTerm t[3];
 };
-struct GradReduceDyn {
-  int n_slabs[HMP_MAX_LAYERS * HMP_MAX_NODE_TYPES];
-  int64_t slab_stride[HMP_MAX_LAYERS * HMP_MAX_NODE_TYPES];
+// slab ids of layer l: l*SLAB_IDS_PER_LAYER + {t: stacked weights of node type t | 8 + t: bias column sums of
+// node type t (GAT) | 16 + c: V_edge of conv c (GAT_edge)}
+constexpr int SLAB_IDS_PER_LAYER = 2 * HMP_MAX_NODE_TYPES + HMP_MAX_CONVS;
+constexpr int GRAD_MAX_SLAB_IDS = HMP_MAX_LAYERS * SLAB_IDS_PER_LAYER;
+struct GradReduceDyn {  // passed by value: keep it small
+  unsigned char n_slabs[GRAD_MAX_SLAB_IDS];
+  int slab_stride[GRAD_MAX_SLAB_IDS];
 };
+
+// ---------------------------------------------------------------------------------------------
+// K3: GAT edge softmax + aggregation
+// ---------------------------------------------------------------------------------------------
+constexpr int GAT_HMAX = 8;
+constexpr int GAT_MAX_EDIM = 4;
+
+// Static (per bound network) description of one GAT layer, resident in device memory: the by-value kernel
+// argument budget (4 KB) cannot hold it.  Everything that changes with the batch travels in GatDyn.
+struct GatInS {
+  int et, src_t;
+  const int *rowptr, *col, *eid, *t_rowptr, *t_col, *t_pos;
+  const float* z;        // projected source rows: h_s (H*Cp) at column hoff
+  int ldz, hoff;
+  const float* za;       // rows holding a_s (H) at column asoff (the executor: za == z)
+  int ldza, asoff;
+  const float* zd;       // projected destination rows: a_d (H) at column adoff
+  int ldzd, adoff;
+  const float* vedge;    // [edim][GAT_HMAX] fold of att_edge into lin_edge, or null
+  int edim;
+  int self_loops;
+  float *smax, *sden;    // [cap_dst, GAT_HMAX] per-row running max / softmax denominator (+1e-16)
+  float adrop_p;
+  uint32_t adrop_stream;
+  float *alpha_drop, *dlogit;  // [cap_E + cap_loop, GAT_HMAX]   (backward)
+  float* dlogit_orig;    // [cap_E, GAT_HMAX] original edge order (edge_attr convs only)
+  float* dza_src;        // rows receiving d a_s at column asoff (the executor: the source dZ)
+  int lddza_src;
+  float* dz_dst;         // destination dZ (d a_d at adoff)
+  int lddz_dst;
+};
+struct GatDstS {
+  int t;
+  int H, C, Cp, concat;
+  float* out;
+  int ldo;
+  const float* bias;     // sum of the convs' biases, width of the output
+  int act;
+  float drop_p;
+  uint32_t drop_stream;
+  float group_scale;     // 1 (HeteroConv sum) or 1/n_convs (mean)
+  const float* g;        // gradient of this layer's output for type t (null: taken from GatDyn.g_top)
+  int ldg;
+  int n_in;
+  GatInS in[AGG_MAX_IN];
+};
+struct GatSrcS {
+  int t;
+  int n_out;
+  struct { int d, i; } out[AGG_MAX_IN];  // (destination entry, in-conv index) pairs leaving this source type
+  float* dz;
+  int lddz;
+};
+struct GatLayerS {
+  int n_dst, n_src;
+  GatDstS d[HMP_MAX_NODE_TYPES];
+  GatSrcS s[HMP_MAX_NODE_TYPES];
+};
+struct GatDyn {
+  int n_nodes[HMP_MAX_NODE_TYPES];
+  long long n_edges[HMP_MAX_EDGE_TYPES];
+  const float* edge_attr[HMP_MAX_EDGE_TYPES];
+  int block_start[HMP_MAX_NODE_TYPES + 1];
+  const float* g_top;    // external output gradient (last layer / autograd path)
+  int ld_gtop;
+  int training;
+  uint32_t k0, k1, step;
+  const int* step_dev;
+};
+int gat_fwd_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
+int gat_bwd1_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
+int gat_bwd2_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
+
 int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t total_elems, const int64_t* d_elem_start,
-                       const GradReduceDyn& dyn, const float* d_slabs, float* d_grads, hipStream_t st);
+                       const GradReduceDyn& dyn, const float* d_slabs, const float* d_params, float* d_grads, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // loss / adam

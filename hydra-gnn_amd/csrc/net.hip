@@ -12,6 +12,11 @@
 //   operand  Wp[l][s] = [ W_l,e1 ; W_l,e2 ; ... ; sum_e W_r,e ]  (Z = x_s * Wp^T), and the aggregation
 //   kernel gathers the (narrow) projected rows.  Weight gradients come back de-stacked; every W_r,e of a
 //   node type receives the same gradient, every b_e the column sum of the destination gradient.
+//
+// GAT algebra: the attention logits a_s = <lin_src(x), att_src> = x * V_src with V_src = fold(att_src, W_src)
+// (and likewise a_d, and the edge term <lin_edge(e), att_edge> = e * V_edge), so the stacked operand of a source
+// type also carries the H rows of V_src^T (and of V_dst^T for the destination role): ONE projection per node
+// type yields h_s, a_s and a_d; the chain rule back to lin/att runs in the gradient un-pack kernel.
 #include <vector>
 
 #include "kernels.h"
@@ -21,20 +26,32 @@ using namespace hmp;
 namespace {
 
 struct ConvLayout {
-  int coff;  // column of this conv's segment in Z[l][src]
+  int coff;               // SAGE: column of W_l * x in Z[l][src];  GAT: column of h_s (H*Cp wide)
+  int asoff, adoff;       // GAT: columns of a_s in Z[l][src] / a_d in Z[l][dst]
+  int H, C, Cp;
+  int64_t vedge_off;      // GAT_edge: packed V_edge [GAT_MAX_EDIM][GAT_HMAX]
+  int64_t vslab_off;      // GAT_edge: slabs of d V_edge
+  bool wd_is_src;         // GAT: the destination role uses lin_src's weights
+  // per-conv workspace (GAT)
+  float *smax, *sden, *alpha_drop, *dlogit, *dlogit_orig;
 };
 
 struct LayerLayout {
+  int kind;
   int n_live;
   int live[HMP_MAX_CONVS];            // indices of live convs
   ConvLayout conv[HMP_MAX_CONVS];
-  int ncols[HMP_MAX_NODE_TYPES];      // width of Z[l][s] (0: type is not a live source / root)
-  int roff[HMP_MAX_NODE_TYPES];       // root segment column in Z[l][t], -1 if t receives nothing
+  int n_in[HMP_MAX_NODE_TYPES];       // live convs reaching the node type
+  int ncols[HMP_MAX_NODE_TYPES];      // width of Z[l][s] (0: type is not read by this layer)
+  int roff[HMP_MAX_NODE_TYPES];       // SAGE root segment column in Z[l][t], -1 if none
   int64_t wp_off[HMP_MAX_NODE_TYPES]; // packed weights [ncols][ldw]
   int ldw[HMP_MAX_NODE_TYPES];
   int64_t bias_off[HMP_MAX_NODE_TYPES];
-  int64_t slab_off[HMP_MAX_NODE_TYPES];  // packed-gradient slabs [max_slabs][ncols][lddw]
+  int64_t slab_off[HMP_MAX_NODE_TYPES];   // packed-gradient slabs [max_slabs][ncols][lddw]
   int lddw[HMP_MAX_NODE_TYPES];
+  int64_t bslab_off[HMP_MAX_NODE_TYPES];  // GAT: slabs of the bias column sums [max_slabs][out_dim][4]
+  GatLayerS* d_gat;                       // device table (GAT layers)
+  GatLayerS h_gat;
 };
 
 constexpr int MAX_SLABS = 16;
@@ -54,6 +71,7 @@ struct hmp_net {
   LayerLayout lay[HMP_MAX_LAYERS];
   int64_t packed_floats, slab_floats;
   int out_dim, out_ld;
+  bool any_gat = false;
 
   // static device tables (owned)
   PackSeg* d_pack_segs = nullptr;
@@ -119,36 +137,71 @@ int build_layout(hmp_net* n) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
     HMP_CHECK_ARG(Ls.n_convs >= 1 && Ls.n_convs <= HMP_MAX_CONVS, "net: layer %d has %d convs", l, Ls.n_convs);
-    HMP_CHECK_ARG(Ls.group_mean == 0, "net: HeteroConv aggr=mean is only supported for GAT pre_mp");
+    Y.kind = Ls.convs[0].kind;
+    Y.d_gat = nullptr;
+    HMP_CHECK_ARG(Y.kind == HMP_CONV_SAGE || Y.kind == HMP_CONV_GAT, "net: layer %d: unknown conv kind %d", l, Y.kind);
+    HMP_CHECK_ARG(Ls.group_mean == 0 || Y.kind == HMP_CONV_GAT, "net: HeteroConv aggr=mean is only supported for GAT layers");
     for (int t = 0; t < n->T; ++t) {
       n->dim[l + 1][t] = Ls.out_dim[t];
       n->ld[l + 1][t] = fpad(Ls.out_dim[t]);
       Y.ncols[t] = 0;
       Y.roff[t] = -1;
+      Y.n_in[t] = 0;
     }
     Y.n_live = 0;
-    int n_in[HMP_MAX_NODE_TYPES] = {0}, n_outgoing[HMP_MAX_NODE_TYPES] = {0};
+    int n_outgoing[HMP_MAX_NODE_TYPES] = {0};
     for (int c = 0; c < Ls.n_convs; ++c) {
       const hmp_conv_spec& C = Ls.convs[c];
-      HMP_CHECK_ARG(C.kind == HMP_CONV_SAGE, "net: layer %d conv %d: only SAGE convs run in this executor build", l, c);
+      ConvLayout& Q = Y.conv[c];
+      memset(&Q, 0, sizeof(Q));
+      HMP_CHECK_ARG(C.kind == Y.kind, "net: layer %d mixes conv kinds", l);
       HMP_CHECK_ARG(C.edge_type >= 0 && C.edge_type < n->ET, "net: conv edge_type");
       HMP_CHECK_ARG(C.src == S.edge_src[C.edge_type] && C.dst == S.edge_dst[C.edge_type], "net: conv endpoints disagree with edge type");
-      HMP_CHECK_ARG(C.f_out == Ls.out_dim[C.dst], "net: SAGE f_out must equal the layer's out_dim of the destination type");
       HMP_CHECK_ARG(n->dim[l][C.src] > 0 && n->dim[l][C.dst] > 0, "net: layer %d conv %d reads a node type with no features", l, c);
+      if (Y.kind == HMP_CONV_SAGE) {
+        HMP_CHECK_ARG(C.f_out == Ls.out_dim[C.dst], "net: SAGE f_out must equal the layer's out_dim of the destination type");
+      } else {
+        HMP_CHECK_ARG(C.heads >= 1 && C.heads <= GAT_HMAX && C.f_out >= 1 && C.f_out <= 256, "net: GAT heads %d / channels %d unsupported", C.heads, C.f_out);
+        HMP_CHECK_ARG(Ls.out_dim[C.dst] == (C.concat ? C.heads * C.f_out : C.f_out), "net: GAT out_dim mismatch on layer %d conv %d", l, c);
+        HMP_CHECK_ARG(C.edge_dim >= 0 && C.edge_dim <= GAT_MAX_EDIM, "net: GAT edge_dim %d > %d", C.edge_dim, GAT_MAX_EDIM);
+        HMP_CHECK_ARG(!(C.edge_dim > 0 && C.fill_mean && C.self_loops), "net: fill_value='mean' with edge attributes is not supported (the reference passes zeros)");
+        HMP_CHECK_ARG(!C.self_loops || C.src == C.dst, "net: self loops need src == dst (the reference sets add_self_loops = (src == dst))");
+      }
       if (!C.active) continue;
-      HMP_CHECK_ARG(C.w0 >= 0 && C.b0 >= 0 && C.w1 >= 0, "net: SAGE conv needs lin_l.weight, lin_l.bias, lin_r.weight");
       Y.live[Y.n_live++] = c;
-      Y.conv[c].coff = Y.ncols[C.src];
-      Y.ncols[C.src] += fpad(C.f_out);
-      ++n_in[C.dst];
+      ++Y.n_in[C.dst];
       ++n_outgoing[C.src];
-      HMP_CHECK_ARG(n_in[C.dst] <= AGG_MAX_IN && n_outgoing[C.src] <= AGG_MAX_IN, "net: more than %d convs share a node type", AGG_MAX_IN);
+      HMP_CHECK_ARG(Y.n_in[C.dst] <= AGG_MAX_IN && n_outgoing[C.src] <= AGG_MAX_IN, "net: more than %d convs share a node type", AGG_MAX_IN);
+      if (Y.kind == HMP_CONV_SAGE) {
+        HMP_CHECK_ARG(C.w0 >= 0 && C.b0 >= 0 && C.w1 >= 0, "net: SAGE conv needs lin_l.weight, lin_l.bias, lin_r.weight");
+        Q.coff = Y.ncols[C.src];
+        Y.ncols[C.src] += fpad(C.f_out);
+      } else {
+        HMP_CHECK_ARG(C.w0 >= 0 && C.a0 >= 0 && C.a1 >= 0 && C.b0 >= 0, "net: GAT conv needs lin_src, att_src, att_dst, bias");
+        HMP_CHECK_ARG(C.edge_dim == 0 || (C.w2 >= 0 && C.a2 >= 0), "net: GAT_edge conv needs lin_edge, att_edge");
+        Q.H = C.heads; Q.C = C.f_out; Q.Cp = fpad(C.f_out);
+        Q.wd_is_src = (C.src == C.dst) || (C.w1 == C.w0) || (C.w1 < 0);
+        HMP_CHECK_ARG(Q.wd_is_src ? (n->dim[l][C.src] == n->dim[l][C.dst]) : true, "net: shared lin with different widths");
+        Q.coff = Y.ncols[C.src];
+        Y.ncols[C.src] += Q.H * Q.Cp;
+        Q.asoff = Y.ncols[C.src];
+        Y.ncols[C.src] += fpad(Q.H);
+        n->any_gat = true;
+      }
     }
     HMP_CHECK_ARG(Y.n_live > 0, "net: layer %d has no live conv", l);
-    for (int t = 0; t < n->T; ++t) {
-      if (n_in[t] > 0) {
-        Y.roff[t] = Y.ncols[t];
-        Y.ncols[t] += fpad(Ls.out_dim[t]);
+    if (Y.kind == HMP_CONV_SAGE) {
+      for (int t = 0; t < n->T; ++t)
+        if (Y.n_in[t] > 0) {
+          Y.roff[t] = Y.ncols[t];
+          Y.ncols[t] += fpad(Ls.out_dim[t]);
+        }
+    } else {
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        const hmp_conv_spec& C = Ls.convs[c];
+        Y.conv[c].adoff = Y.ncols[C.dst];
+        Y.ncols[C.dst] += fpad(C.heads);
       }
     }
     for (int t = 0; t < n->T; ++t) {
@@ -157,9 +210,22 @@ int build_layout(hmp_net* n) {
       Y.wp_off[t] = packed;
       packed += (int64_t)Y.ncols[t] * Y.ldw[t];
       Y.bias_off[t] = packed;
-      packed += (Y.roff[t] >= 0) ? fpad(Ls.out_dim[t]) : 0;
+      packed += (Y.n_in[t] > 0) ? fpad(Ls.out_dim[t]) : 0;
       Y.slab_off[t] = slabs;
       slabs += (int64_t)MAX_SLABS * Y.ncols[t] * Y.lddw[t];
+      Y.bslab_off[t] = slabs;
+      if (Y.kind == HMP_CONV_GAT && Y.n_in[t] > 0) slabs += (int64_t)MAX_SLABS * fpad(Ls.out_dim[t]) * 4;
+    }
+    if (Y.kind == HMP_CONV_GAT) {
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        if (Ls.convs[c].edge_dim > 0) {
+          Y.conv[c].vedge_off = packed;
+          packed += GAT_MAX_EDIM * GAT_HMAX;
+          Y.conv[c].vslab_off = slabs;
+          slabs += (int64_t)MAX_SLABS * GAT_MAX_EDIM * GAT_HMAX;
+        }
+      }
     }
   }
   // liveness must be closed: whatever a live conv produces is consumed by the next layer / the readout
@@ -181,6 +247,19 @@ int build_layout(hmp_net* n) {
   return HMP_OK;
 }
 
+inline int slab_id_w(int l, int t) { return l * SLAB_IDS_PER_LAYER + t; }
+inline int slab_id_b(int l, int t) { return l * SLAB_IDS_PER_LAYER + HMP_MAX_NODE_TYPES + t; }
+inline int slab_id_v(int l, int c) { return l * SLAB_IDS_PER_LAYER + 2 * HMP_MAX_NODE_TYPES + c; }
+
+GradTerm term(int kind, int slab_id, int64_t src, int ld, int C, int Cp, int inner = 0, int64_t att = 0, int64_t w = 0, int ldw = 0,
+              float scale = 1.f) {
+  GradTerm t;
+  memset(&t, 0, sizeof(t));
+  t.kind = kind; t.slab_id = slab_id; t.src = src; t.ld = ld; t.C = C; t.Cp = Cp; t.inner = inner;
+  t.att = att; t.w = w; t.ldw = ldw; t.scale = scale;
+  return t;
+}
+
 // static pack / grad tables ------------------------------------------------------------------------
 int build_tables(hmp_net* n) {
   const hmp_net_spec& S = n->spec;
@@ -189,52 +268,127 @@ int build_tables(hmp_net* n) {
   std::vector<GradSeg> gs;
   std::vector<int64_t> ges;
   int64_t prow = 0, gel = 0;
+  auto push_pack = [&](const PackSeg& s) { ps.push_back(s); prs.push_back(prow); prow += s.rows_pad; };
+  auto push_grad = [&](GradSeg g) { gs.push_back(g); ges.push_back(gel); gel += (int64_t)g.rows * g.cols; };
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
     const LayerLayout& Y = n->lay[l];
-    for (int i = 0; i < Y.n_live; ++i) {  // W_l segments
+    const float gscale = Ls.group_mean ? 1.f : 1.f;  // weights see the scale through the output gradient; bias below
+    (void)gscale;
+    for (int i = 0; i < Y.n_live; ++i) {
       const int c = Y.live[i];
       const hmp_conv_spec& C = Ls.convs[c];
-      const int fs = n->dim[l][C.src];
+      const ConvLayout& Q = Y.conv[c];
+      const int fs = n->dim[l][C.src], ft = n->dim[l][C.dst];
       PackSeg s;
       memset(&s, 0, sizeof(s));
-      s.dst = Y.wp_off[C.src] + (int64_t)Y.conv[c].coff * Y.ldw[C.src];
-      s.rows = C.f_out; s.rows_pad = fpad(C.f_out); s.cols = fs; s.ld_dst = Y.ldw[C.src]; s.ld_src = fs;
+      if (Y.kind == HMP_CONV_SAGE) {
+        s.kind = PACK_SUM;
+        s.dst = Y.wp_off[C.src] + (int64_t)Q.coff * Y.ldw[C.src];
+        s.rows = C.f_out; s.rows_pad = fpad(C.f_out); s.cols = fs; s.ld_dst = Y.ldw[C.src]; s.ld_src = fs;
+        s.nsrc = 1; s.src[0] = C.w0;
+        push_pack(s);
+        GradSeg g;
+        memset(&g, 0, sizeof(g));
+        g.dst = C.w0; g.rows = C.f_out; g.cols = fs; g.n_terms = 1;
+        g.t[0] = term(GT_COPY, slab_id_w(l, C.src), Y.slab_off[C.src] + (int64_t)Q.coff * Y.lddw[C.src], Y.lddw[C.src], C.f_out, C.f_out);
+        push_grad(g);
+        continue;
+      }
+      // ---- GAT conv -------------------------------------------------------------------------------
+      const int HC = Q.H * Q.C;
+      const int64_t wd = Q.wd_is_src ? C.w0 : C.w1;
+      // h_s rows (heads padded to Cp)
+      s.kind = PACK_HEADS; s.H = Q.H; s.C = Q.C; s.Cp = Q.Cp;
+      s.dst = Y.wp_off[C.src] + (int64_t)Q.coff * Y.ldw[C.src];
+      s.rows = Q.H * Q.Cp; s.rows_pad = Q.H * Q.Cp; s.cols = fs; s.ld_dst = Y.ldw[C.src]; s.ld_src = fs;
       s.nsrc = 1; s.src[0] = C.w0;
-      ps.push_back(s); prs.push_back(prow); prow += s.rows_pad;
+      push_pack(s);
+      // V_src^T rows
+      s.kind = PACK_ATTDOT; s.dst = Y.wp_off[C.src] + (int64_t)Q.asoff * Y.ldw[C.src];
+      s.rows = Q.H; s.rows_pad = fpad(Q.H); s.att = C.a0; s.src[0] = C.w0;
+      push_pack(s);
+      // V_dst^T rows (destination role)
+      s.dst = Y.wp_off[C.dst] + (int64_t)Q.adoff * Y.ldw[C.dst];
+      s.cols = ft; s.ld_dst = Y.ldw[C.dst]; s.ld_src = ft; s.att = C.a1; s.src[0] = wd;
+      push_pack(s);
+      if (C.edge_dim > 0) {
+        s.kind = PACK_ATTDOT_T; s.dst = Q.vedge_off; s.rows = C.edge_dim; s.rows_pad = GAT_MAX_EDIM; s.cols = Q.H;
+        s.ld_dst = GAT_HMAX; s.ld_src = C.edge_dim; s.att = C.a2; s.src[0] = C.w2;
+        push_pack(s);
+      }
+      const int64_t S_hs = Y.slab_off[C.src] + (int64_t)Q.coff * Y.lddw[C.src];
+      const int64_t S_as = Y.slab_off[C.src] + (int64_t)Q.asoff * Y.lddw[C.src];
+      const int64_t S_ad = Y.slab_off[C.dst] + (int64_t)Q.adoff * Y.lddw[C.dst];
       GradSeg g;
-      g.dst = C.w0; g.rows = C.f_out; g.cols = fs;
-      g.src = Y.slab_off[C.src] + (int64_t)Y.conv[c].coff * Y.lddw[C.src];
-      g.ld_src = Y.lddw[C.src]; g.slab_id = l * HMP_MAX_NODE_TYPES + C.src;
-      gs.push_back(g); ges.push_back(gel); gel += (int64_t)g.rows * g.cols;
+      memset(&g, 0, sizeof(g));
+      // lin_src.weight
+      g.dst = C.w0; g.rows = HC; g.cols = fs;
+      g.t[g.n_terms++] = term(GT_COPY, slab_id_w(l, C.src), S_hs, Y.lddw[C.src], Q.C, Q.Cp);
+      g.t[g.n_terms++] = term(GT_ATT_OUTER, slab_id_w(l, C.src), S_as, Y.lddw[C.src], Q.C, Q.C, 0, C.a0);
+      if (Q.wd_is_src) g.t[g.n_terms++] = term(GT_ATT_OUTER, slab_id_w(l, C.dst), S_ad, Y.lddw[C.dst], Q.C, Q.C, 0, C.a1);
+      push_grad(g);
+      if (!Q.wd_is_src) {  // separate lin_dst.weight
+        memset(&g, 0, sizeof(g));
+        g.dst = C.w1; g.rows = HC; g.cols = ft; g.n_terms = 1;
+        g.t[0] = term(GT_ATT_OUTER, slab_id_w(l, C.dst), S_ad, Y.lddw[C.dst], Q.C, Q.C, 0, C.a1);
+        push_grad(g);
+      }
+      memset(&g, 0, sizeof(g));  // att_src
+      g.dst = C.a0; g.rows = HC; g.cols = 1; g.n_terms = 1;
+      g.t[0] = term(GT_ATT_DOT, slab_id_w(l, C.src), S_as, Y.lddw[C.src], Q.C, Q.C, fs, 0, C.w0, fs);
+      push_grad(g);
+      memset(&g, 0, sizeof(g));  // att_dst
+      g.dst = C.a1; g.rows = HC; g.cols = 1; g.n_terms = 1;
+      g.t[0] = term(GT_ATT_DOT, slab_id_w(l, C.dst), S_ad, Y.lddw[C.dst], Q.C, Q.C, ft, 0, wd, ft);
+      push_grad(g);
+      if (C.edge_dim > 0) {
+        memset(&g, 0, sizeof(g));  // lin_edge.weight [HC, D]
+        g.dst = C.w2; g.rows = HC; g.cols = C.edge_dim; g.n_terms = 1;
+        g.t[0] = term(GT_ATT_OUTER_T, slab_id_v(l, c), Q.vslab_off, GAT_HMAX, Q.C, Q.C, 0, C.a2);
+        push_grad(g);
+        memset(&g, 0, sizeof(g));  // att_edge
+        g.dst = C.a2; g.rows = HC; g.cols = 1; g.n_terms = 1;
+        g.t[0] = term(GT_ATT_DOT_T, slab_id_v(l, c), Q.vslab_off, GAT_HMAX, Q.C, Q.C, C.edge_dim, 0, C.w2, C.edge_dim);
+        push_grad(g);
+      }
+      memset(&g, 0, sizeof(g));  // bias: column sums of the destination gradient
+      const int wout = Ls.out_dim[C.dst];
+      g.dst = C.b0; g.rows = wout; g.cols = 1; g.n_terms = 1;
+      g.t[0] = term(GT_COPY, slab_id_b(l, C.dst), Y.bslab_off[C.dst], 4, wout, wout, 0, 0, 0, 0,
+                    Ls.group_mean ? 1.f / (float)Y.n_in[C.dst] : 1.f);
+      push_grad(g);
     }
-    for (int t = 0; t < n->T; ++t) {  // root + bias segments
-      if (Y.roff[t] < 0) continue;
+    for (int t = 0; t < n->T; ++t) {  // per destination type: SAGE root + bias sums, GAT bias sums
+      if (Y.n_in[t] == 0) continue;
       const int fo = Ls.out_dim[t], ft = n->dim[l][t];
       PackSeg s, b;
       memset(&s, 0, sizeof(s));
       memset(&b, 0, sizeof(b));
-      s.dst = Y.wp_off[t] + (int64_t)Y.roff[t] * Y.ldw[t];
+      s.kind = PACK_SUM; b.kind = PACK_SUM;
+      s.dst = Y.wp_off[t] + (int64_t)(Y.roff[t] < 0 ? 0 : Y.roff[t]) * Y.ldw[t];
       s.rows = fo; s.rows_pad = fpad(fo); s.cols = ft; s.ld_dst = Y.ldw[t]; s.ld_src = ft;
       b.dst = Y.bias_off[t];
       b.rows = 1; b.rows_pad = 1; b.cols = fo; b.ld_dst = fpad(fo); b.ld_src = fo;
       for (int i = 0; i < Y.n_live; ++i) {
         const hmp_conv_spec& C = Ls.convs[Y.live[i]];
         if (C.dst != t) continue;
-        s.src[s.nsrc++] = C.w1;
         b.src[b.nsrc++] = C.b0;
+        if (Y.kind != HMP_CONV_SAGE) continue;
+        s.src[s.nsrc++] = C.w1;
         GradSeg g;
-        g.dst = C.w1; g.rows = fo; g.cols = ft;
-        g.src = Y.slab_off[t] + (int64_t)Y.roff[t] * Y.lddw[t];
-        g.ld_src = Y.lddw[t]; g.slab_id = l * HMP_MAX_NODE_TYPES + t;
-        gs.push_back(g); ges.push_back(gel); gel += (int64_t)g.rows * g.cols;
-        GradSeg gb;  // bias: the ones-column (index ft) of the root rows
-        gb.dst = C.b0; gb.rows = fo; gb.cols = 1;
-        gb.src = g.src + ft; gb.ld_src = Y.lddw[t]; gb.slab_id = g.slab_id;
-        gs.push_back(gb); ges.push_back(gel); gel += fo;
+        memset(&g, 0, sizeof(g));
+        g.dst = C.w1; g.rows = fo; g.cols = ft; g.n_terms = 1;
+        const int64_t root = Y.slab_off[t] + (int64_t)Y.roff[t] * Y.lddw[t];
+        g.t[0] = term(GT_COPY, slab_id_w(l, t), root, Y.lddw[t], fo, fo);
+        push_grad(g);
+        memset(&g, 0, sizeof(g));  // bias: the ones-column (index ft) of the root rows
+        g.dst = C.b0; g.rows = fo; g.cols = 1; g.n_terms = 1;
+        g.t[0] = term(GT_COPY, slab_id_w(l, t), root + ft, Y.lddw[t], fo, fo);
+        push_grad(g);
       }
-      ps.push_back(s); prs.push_back(prow); prow += s.rows_pad;
-      ps.push_back(b); prs.push_back(prow); prow += 1;
+      if (Y.kind == HMP_CONV_SAGE) push_pack(s);
+      push_pack(b);
     }
   }
   prs.push_back(prow);
@@ -249,6 +403,8 @@ int build_tables(hmp_net* n) {
   HMP_HIP(hipMemcpy(n->d_pack_row_start, prs.data(), prs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   HMP_HIP(hipMemcpy(n->d_grad_segs, gs.data(), gs.size() * sizeof(GradSeg), hipMemcpyHostToDevice));
   HMP_HIP(hipMemcpy(n->d_grad_elem_start, ges.data(), ges.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  for (int l = 0; l < n->L; ++l)
+    if (n->lay[l].kind == HMP_CONV_GAT) HMP_HIP(hipMalloc(&n->lay[l].d_gat, sizeof(GatLayerS)));
   return HMP_OK;
 }
 
@@ -283,20 +439,110 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
         n->G[l][t] = (float*)take((size_t)cn[t] * n->ld[l][t] * 4);
       }
     }
-  for (int l = 0; l < n->L; ++l)
+  for (int l = 0; l < n->L; ++l) {
+    LayerLayout& Y = n->lay[l];
     for (int t = 0; t < n->T; ++t) {
       n->Z[l][t] = n->dZ[l][t] = nullptr;
-      if (n->lay[l].ncols[t] > 0) {
-        n->Z[l][t] = (float*)take((size_t)cn[t] * n->lay[l].ncols[t] * 4);
-        n->dZ[l][t] = (float*)take((size_t)cn[t] * n->lay[l].ncols[t] * 4);
+      if (Y.ncols[t] > 0) {
+        n->Z[l][t] = (float*)take((size_t)cn[t] * Y.ncols[t] * 4);
+        n->dZ[l][t] = (float*)take((size_t)cn[t] * Y.ncols[t] * 4);
       }
     }
+    if (Y.kind != HMP_CONV_GAT) continue;
+    for (int i = 0; i < Y.n_live; ++i) {
+      const int c = Y.live[i];
+      const hmp_conv_spec& C = S.layers[l].convs[c];
+      ConvLayout& Q = Y.conv[c];
+      const size_t nd = (size_t)cn[C.dst], ne = (size_t)ce[C.edge_type] + (C.self_loops ? nd : 0);
+      Q.smax = (float*)take(nd * GAT_HMAX * 4);
+      Q.sden = (float*)take(nd * GAT_HMAX * 4);
+      Q.alpha_drop = (float*)take(ne * GAT_HMAX * 4);
+      Q.dlogit = (float*)take(ne * GAT_HMAX * 4);
+      Q.dlogit_orig = C.edge_dim > 0 ? (float*)take((size_t)ce[C.edge_type] * GAT_HMAX * 4) : nullptr;
+    }
+  }
   int cap_out = cn[S.readout_type];
   if (S.pool_edge_type >= 0) cap_out = cn[S.edge_dst[S.pool_edge_type]];
   n->cap_out = cap_out;
   n->d_out = (float*)take((size_t)cap_out * n->out_ld * 4);
   n->d_gout = (float*)take((size_t)cap_out * n->out_ld * 4);
   return off;
+}
+
+// device tables of the GAT layers (hold workspace pointers => built when the workspace is bound)
+int build_gat_tables(hmp_net* n) {
+  const hmp_net_spec& S = n->spec;
+  for (int l = 0; l < n->L; ++l) {
+    LayerLayout& Y = n->lay[l];
+    if (Y.kind != HMP_CONV_GAT) continue;
+    const hmp_layer_spec& Ls = S.layers[l];
+    GatLayerS& G = Y.h_gat;
+    memset(&G, 0, sizeof(G));
+    int dst_entry[HMP_MAX_NODE_TYPES];
+    for (int t = 0; t < n->T; ++t) {
+      dst_entry[t] = -1;
+      if (Y.n_in[t] == 0) continue;
+      dst_entry[t] = G.n_dst;
+      GatDstS& D = G.d[G.n_dst++];
+      D.t = t;
+      D.out = n->H[l + 1][t]; D.ldo = n->ld[l + 1][t];
+      D.bias = n->d_packed + Y.bias_off[t];
+      D.act = Ls.act;
+      D.drop_p = Ls.dropout;
+      D.drop_stream = (uint32_t)(l * HMP_MAX_NODE_TYPES + t);
+      D.group_scale = Ls.group_mean ? 1.f / (float)Y.n_in[t] : 1.f;
+      const bool top = (l == n->L - 1);
+      D.g = top ? nullptr : n->G[l + 1][t];
+      D.ldg = n->ld[l + 1][t];
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        const hmp_conv_spec& C = Ls.convs[c];
+        if (C.dst != t) continue;
+        const ConvLayout& Q = Y.conv[c];
+        if (D.n_in == 0) { D.H = Q.H; D.C = Q.C; D.Cp = Q.Cp; D.concat = C.concat; }
+        HMP_CHECK_ARG(D.H == Q.H && D.C == Q.C && D.concat == C.concat, "net: GAT convs reaching one node type must share heads/channels/concat");
+        GatInS& I = D.in[D.n_in++];
+        const hmp_plan& P = n->plan[C.edge_type];
+        I.et = C.edge_type; I.src_t = C.src;
+        I.rowptr = P.d_rowptr; I.col = P.d_col; I.eid = P.d_eid;
+        I.t_rowptr = P.d_t_rowptr; I.t_col = P.d_t_col; I.t_pos = P.d_t_pos;
+        I.z = n->Z[l][C.src]; I.ldz = Y.ncols[C.src]; I.hoff = Q.coff;
+        I.za = I.z; I.ldza = I.ldz; I.asoff = Q.asoff;
+        I.zd = n->Z[l][t]; I.ldzd = Y.ncols[t]; I.adoff = Q.adoff;
+        I.edim = C.edge_dim;
+        I.vedge = C.edge_dim > 0 ? n->d_packed + Q.vedge_off : nullptr;
+        I.self_loops = C.self_loops;
+        I.smax = Q.smax; I.sden = Q.sden;
+        I.adrop_p = C.att_dropout;
+        I.adrop_stream = (uint32_t)(1000 + l * HMP_MAX_CONVS + c);
+        I.alpha_drop = Q.alpha_drop; I.dlogit = Q.dlogit; I.dlogit_orig = Q.dlogit_orig;
+        I.dza_src = n->dZ[l][C.src]; I.lddza_src = Y.ncols[C.src];
+        I.dz_dst = n->dZ[l][t]; I.lddz_dst = Y.ncols[t];
+      }
+    }
+    for (int s = 0; s < n->T; ++s) {
+      GatSrcS* Sx = nullptr;
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        const hmp_conv_spec& C = Ls.convs[c];
+        if (C.src != s) continue;
+        if (!Sx) {
+          Sx = &G.s[G.n_src++];
+          Sx->t = s; Sx->dz = n->dZ[l][s]; Sx->lddz = Y.ncols[s];
+        }
+        // locate the in-conv index inside the destination entry
+        const GatDstS& D = G.d[dst_entry[C.dst]];
+        int ii = -1;
+        for (int q = 0; q < D.n_in; ++q)
+          if (D.in[q].et == C.edge_type) ii = q;
+        Sx->out[Sx->n_out].d = dst_entry[C.dst];
+        Sx->out[Sx->n_out].i = ii;
+        ++Sx->n_out;
+      }
+    }
+    HMP_HIP(hipMemcpy(Y.d_gat, &G, sizeof(G), hipMemcpyHostToDevice));
+  }
+  return HMP_OK;
 }
 
 // profiling helpers ------------------------------------------------------------------------------------
@@ -309,12 +555,12 @@ struct Scope {
     ProfRec r;
     r.cls = cls;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     n->recs.push_back(r);
     idx = (int)n->recs.size() - 1;
   }
   ~Scope() {
-    if (idx >= 0) hipEventRecord(n->recs[idx].b, st);
+    if (idx >= 0) (void)hipEventRecord(n->recs[idx].b, st);
   }
 };
 
@@ -325,6 +571,18 @@ DropCfg make_drop(const hmp_net* n, float p, uint32_t stream) {
   d.k0 = (uint32_t)n->seed; d.k1 = (uint32_t)(n->seed >> 32);
   d.step = n->rng_step; d.stream = stream;
   d.thresh = drop_thresh(p); d.scale = 1.f / (1.f - p);
+  d.step_dev = n->step_dev ? &n->d_state->step : nullptr;
+  return d;
+}
+
+GatDyn make_gat_dyn(const hmp_net* n, const hmp_batch* b) {
+  GatDyn d;
+  memset(&d, 0, sizeof(d));
+  for (int t = 0; t < n->T; ++t) d.n_nodes[t] = b->n_nodes[t];
+  for (int e = 0; e < n->ET; ++e) { d.n_edges[e] = b->n_edges[e]; d.edge_attr[e] = b->d_edge_attr[e]; }
+  d.training = n->training;
+  d.k0 = (uint32_t)n->seed; d.k1 = (uint32_t)(n->seed >> 32);
+  d.step = n->rng_step;
   d.step_dev = n->step_dev ? &n->d_state->step : nullptr;
   return d;
 }
@@ -340,6 +598,14 @@ int check_batch(const hmp_net* n, const hmp_batch* b) {
   for (int e = 0; e < n->ET; ++e) {
     HMP_CHECK_ARG(b->n_edges[e] >= 0 && b->n_edges[e] <= n->cap_edges[e], "batch: edge type %d has %lld edges, capacity %lld", e, (long long)b->n_edges[e], (long long)n->cap_edges[e]);
     HMP_CHECK_ARG(b->n_edges[e] == 0 || b->d_edge_index[e] != nullptr, "batch: edge type %d edge_index missing", e);
+  }
+  for (int l = 0; l < n->L; ++l) {
+    const LayerLayout& Y = n->lay[l];
+    for (int i = 0; i < Y.n_live; ++i) {
+      const hmp_conv_spec& C = S.layers[l].convs[Y.live[i]];
+      if (C.kind == HMP_CONV_GAT && C.edge_dim > 0 && b->n_edges[C.edge_type] > 0)
+        HMP_CHECK_ARG(b->d_edge_attr[C.edge_type] != nullptr, "batch: edge type %d needs edge_attr [E, %d]", C.edge_type, C.edge_dim);
+    }
   }
   const int n_out_expect = S.pool_edge_type >= 0 ? b->n_nodes[S.edge_dst[S.pool_edge_type]] : b->n_nodes[S.readout_type];
   HMP_CHECK_ARG(b->n_out == n_out_expect, "batch: n_out %d != %d", b->n_out, n_out_expect);
@@ -370,6 +636,20 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
 const float* h_ptr(const hmp_net* n, int l, int t) { return l == 0 ? n->batch.d_x[t] : n->H[l][t]; }
 int h_ld(const hmp_net* n, int l, int t) { return l == 0 ? n->batch.ldx[t] : n->ld[l][t]; }
 
+// launches a list of GEMM problems in groups of GEMM_MAX_PROB; ksplit_out receives the split of each problem
+int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out) {
+  for (size_t base = 0; base < ps.size(); base += GEMM_MAX_PROB) {
+    GemmBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    const size_t cnt = (ps.size() - base) < (size_t)GEMM_MAX_PROB ? (ps.size() - base) : (size_t)GEMM_MAX_PROB;
+    for (size_t i = 0; i < cnt; ++i) gb.p[gb.n++] = ps[base + i];
+    HMP_TRY(gemm_launch(gb, want_split, MAX_SLABS, st));
+    if (ksplit_out)
+      for (size_t i = 0; i < cnt; ++i) ksplit_out->push_back(gb.p[i].ksplit);
+  }
+  return HMP_OK;
+}
+
 int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStream_t st) {
   HMP_TRY(check_batch(n, b));
   n->batch = *b;
@@ -381,22 +661,29 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   }
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
-    const LayerLayout& Y = n->lay[l];
+    LayerLayout& Y = n->lay[l];
     {  // grouped projection
       Scope sc(n, KC_GEMM_FWD, st);
-      GemmBatch gb;
-      memset(&gb, 0, sizeof(gb));
+      std::vector<GemmProblem> ps;
       for (int s = 0; s < n->T; ++s) {
         if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
-        GemmProblem& p = gb.p[gb.n++];
+        GemmProblem p;
+        memset(&p, 0, sizeof(p));
         p.A = h_ptr(n, l, s); p.lda = h_ld(n, l, s); p.trans_a = 0;
         p.B = n->d_packed + Y.wp_off[s]; p.ldb = Y.ldw[s]; p.trans_b = 1;
         p.C = n->Z[l][s]; p.ldc = Y.ncols[s];
         p.M = b->n_nodes[s]; p.N = Y.ncols[s]; p.K = n->dim[l][s];
         p.n_real = p.N;
         p.epi = EPI_NONE;
+        ps.push_back(p);
       }
-      HMP_TRY(gemm_launch(gb, false, 1, st));
+      HMP_TRY(gemm_many(ps, false, st, nullptr));
+    }
+    if (Y.kind == HMP_CONV_GAT) {
+      Scope sc(n, KC_GAT_FWD, st);
+      GatDyn dyn = make_gat_dyn(n, b);
+      HMP_TRY(gat_fwd_launch(Y.d_gat, Y.h_gat, dyn, st));
+      continue;
     }
     {  // fused aggregation + root + bias + activation + dropout
       Scope sc(n, KC_AGG_FWD, st);
@@ -442,7 +729,8 @@ const float* out_ptr(const hmp_net* n) {
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
-int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, float* const* d_gx, hipStream_t st) {
+int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, const float* d_params, float* const* d_gx,
+                  hipStream_t st) {
   HMP_CHECK_ARG(n->have_fwd, "net: backward without a forward");
   HMP_CHECK_ARG((ld_gout & 3) == 0 && ld_gout >= n->out_ld && (reinterpret_cast<uintptr_t>(d_gout) & 15) == 0,
                 "net: output gradient must be 16-byte aligned with ld %% 4 == 0 and ld >= %d", n->out_ld);
@@ -460,13 +748,19 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   memset(&n->dyn, 0, sizeof(n->dyn));
   for (int l = n->L - 1; l >= 0; --l) {
     const hmp_layer_spec& Ls = S.layers[l];
-    const LayerLayout& Y = n->lay[l];
+    LayerLayout& Y = n->lay[l];
     auto g_of = [&](int t, int& ldg) -> const float* {
       if (l == n->L - 1 && t == rt) { ldg = ld_gtop; return gtop; }
       ldg = n->ld[l + 1][t];
       return n->G[l + 1][t];
     };
-    {  // transposed aggregation: gradient of the projected rows
+    if (Y.kind == HMP_CONV_GAT) {
+      Scope sc(n, KC_GAT_BWD, st);
+      GatDyn dyn = make_gat_dyn(n, b);
+      dyn.g_top = gtop; dyn.ld_gtop = ld_gtop;
+      HMP_TRY(gat_bwd1_launch(Y.d_gat, Y.h_gat, dyn, st));
+      HMP_TRY(gat_bwd2_launch(Y.d_gat, Y.h_gat, dyn, st));
+    } else {  // transposed aggregation: gradient of the projected rows
       Scope sc(n, KC_AGG_BWD, st);
       TAggArgs a;
       memset(&a, 0, sizeof(a));
@@ -498,13 +792,13 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     const bool need_dx = (l > 0) || (d_gx != nullptr);
     if (need_dx) {  // input gradient, masked by the previous layer's activation/dropout derivative
       Scope sc(n, KC_GEMM_BWD, st);
-      GemmBatch gb;
-      memset(&gb, 0, sizeof(gb));
+      std::vector<GemmProblem> ps;
       for (int s = 0; s < n->T; ++s) {
         if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
         float* dst = l > 0 ? n->G[l][s] : d_gx[s];
         if (!dst) continue;
-        GemmProblem& p = gb.p[gb.n++];
+        GemmProblem p;
+        memset(&p, 0, sizeof(p));
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 0;
         p.B = n->d_packed + Y.wp_off[s]; p.ldb = Y.ldw[s]; p.trans_b = 0;
         p.C = dst; p.ldc = l > 0 ? n->ld[l][s] : b->ldx[s];
@@ -518,37 +812,69 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           if (p.drop_on) p.drop = make_drop(n, Lp.dropout, (uint32_t)((l - 1) * HMP_MAX_NODE_TYPES + s));
           if (p.act == HMP_ACT_NONE && !p.drop_on) p.epi = EPI_NONE;
         }
+        ps.push_back(p);
       }
-      HMP_TRY(gemm_launch(gb, false, 1, st));
+      HMP_TRY(gemm_many(ps, false, st, nullptr));
     }
-    {  // weight + bias gradient: dWp = dZ^T * [H | 1], split over node chunks
+    {  // weight + bias gradient: dWp = dZ^T * [H | 1], split over node chunks (+ GAT: bias column sums, d V_edge)
       Scope sc(n, KC_GEMM_BWD, st);
-      GemmBatch gb;
-      memset(&gb, 0, sizeof(gb));
-      int ids[GEMM_MAX_PROB];
+      std::vector<GemmProblem> ps;
+      std::vector<int> ids;
+      auto add = [&](int sid, const GemmProblem& p) {
+        n->dyn.slab_stride[sid] = (int)p.slab_stride;
+        ids.push_back(sid);
+        ps.push_back(p);
+      };
       for (int s = 0; s < n->T; ++s) {
-        if (Y.ncols[s] == 0) continue;
-        const int sid = l * HMP_MAX_NODE_TYPES + s;
-        n->dyn.n_slabs[sid] = 0;
-        n->dyn.slab_stride[sid] = (int64_t)Y.ncols[s] * Y.lddw[s];
-        if (b->n_nodes[s] == 0) continue;  // no nodes: zero gradient (n_slabs = 0)
-        ids[gb.n] = sid;
-        GemmProblem& p = gb.p[gb.n++];
+        if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;  // no nodes: zero gradient (n_slabs stays 0)
+        GemmProblem p;
+        memset(&p, 0, sizeof(p));
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 1;
         p.B = h_ptr(n, l, s); p.ldb = h_ld(n, l, s); p.trans_b = 0;
         p.C = n->d_slabs + Y.slab_off[s]; p.ldc = Y.lddw[s];
         p.slab_stride = (int64_t)Y.ncols[s] * Y.lddw[s];
         p.M = Y.ncols[s]; p.N = n->dim[l][s] + 1; p.K = b->n_nodes[s];
         p.n_real = n->dim[l][s]; p.aug_ones = 1;
-        p.epi = EPI_NONE;
+        add(slab_id_w(l, s), p);
       }
-      HMP_TRY(gemm_launch(gb, true, MAX_SLABS, st));
-      for (int i = 0; i < gb.n; ++i) n->dyn.n_slabs[ids[i]] = gb.p[i].ksplit;
+      if (Y.kind == HMP_CONV_GAT) {
+        for (int t = 0; t < n->T; ++t) {  // bias: column sums of the output gradient
+          if (Y.n_in[t] == 0 || b->n_nodes[t] == 0) continue;
+          int ldg;
+          const float* g = g_of(t, ldg);
+          GemmProblem p;
+          memset(&p, 0, sizeof(p));
+          p.A = g; p.lda = ldg; p.trans_a = 1;
+          p.B = g; p.ldb = ldg; p.trans_b = 0;  // no real columns are read (n_real = 0): only the ones column
+          p.C = n->d_slabs + Y.bslab_off[t]; p.ldc = 4;
+          p.slab_stride = (int64_t)fpad(Ls.out_dim[t]) * 4;
+          p.M = Ls.out_dim[t]; p.N = 1; p.K = b->n_nodes[t];
+          p.n_real = 0; p.aug_ones = 1;
+          add(slab_id_b(l, t), p);
+        }
+        for (int i = 0; i < Y.n_live; ++i) {  // d V_edge = edge_attr^T * d logit (original edge order)
+          const int c = Y.live[i];
+          const hmp_conv_spec& C = Ls.convs[c];
+          if (C.edge_dim == 0 || b->n_edges[C.edge_type] == 0) continue;
+          GemmProblem p;
+          memset(&p, 0, sizeof(p));
+          p.A = b->d_edge_attr[C.edge_type]; p.lda = C.edge_dim; p.trans_a = 1;
+          p.B = Y.conv[c].dlogit_orig; p.ldb = GAT_HMAX; p.trans_b = 0;
+          p.C = n->d_slabs + Y.conv[c].vslab_off; p.ldc = GAT_HMAX;
+          p.slab_stride = GAT_MAX_EDIM * GAT_HMAX;
+          p.M = C.edge_dim; p.N = C.heads; p.K = (int)b->n_edges[C.edge_type];
+          p.n_real = C.heads;
+          add(slab_id_v(l, c), p);
+        }
+      }
+      std::vector<int> ks;
+      HMP_TRY(gemm_many(ps, true, st, &ks));
+      for (size_t i = 0; i < ids.size(); ++i) n->dyn.n_slabs[ids[i]] = (unsigned char)ks[i];
     }
   }
   {
     Scope sc(n, KC_GRAD_REDUCE, st);
-    HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->n_grad, n->grad_elems, n->d_grad_elem_start, n->dyn, n->d_slabs, d_grads, st));
+    HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->n_grad, n->grad_elems, n->d_grad_elem_start, n->dyn, n->d_slabs, d_params, d_grads, st));
   }
   return HMP_OK;
 }
@@ -575,11 +901,13 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
 
 extern "C" void hmp_net_destroy(hmp_net* n) {
   if (!n) return;
-  for (auto& r : n->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-  if (n->d_pack_segs) hipFree(n->d_pack_segs);
-  if (n->d_pack_row_start) hipFree(n->d_pack_row_start);
-  if (n->d_grad_segs) hipFree(n->d_grad_segs);
-  if (n->d_grad_elem_start) hipFree(n->d_grad_elem_start);
+  for (auto& r : n->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  if (n->d_pack_segs) (void)hipFree(n->d_pack_segs);
+  if (n->d_pack_row_start) (void)hipFree(n->d_pack_row_start);
+  if (n->d_grad_segs) (void)hipFree(n->d_grad_segs);
+  if (n->d_grad_elem_start) (void)hipFree(n->d_grad_elem_start);
+  for (int l = 0; l < HMP_MAX_LAYERS; ++l)
+    if (l < n->L && n->lay[l].d_gat) (void)hipFree(n->lay[l].d_gat);
   delete n;
 }
 
@@ -599,6 +927,7 @@ extern "C" int hmp_net_bind_workspace(hmp_net* n, void* d_workspace, size_t byte
   for (int e = 0; e < n->ET; ++e) n->cap_edges[e] = cap_edges[e];
   // zero once: padding columns of every buffer stay zero for the lifetime of the binding
   HMP_HIP(hipMemset(d_workspace, 0, need));
+  HMP_TRY(build_gat_tables(n));
   n->bound = true;
   n->have_fwd = false;
   return HMP_OK;
@@ -617,7 +946,7 @@ extern "C" int hmp_net_forward(hmp_net* n, const hmp_batch* batch, const float* 
 extern "C" int hmp_net_backward(hmp_net* n, const float* d_gout, int32_t ld_gout, const float* d_params, float* d_grads,
                                 float* const* d_gx, void* stream) {
   HMP_CHECK_ARG(n && d_gout && d_grads && d_params, "hmp_net_backward: null argument");
-  return backward_impl(n, d_gout, ld_gout, d_grads, d_gx, (hipStream_t)stream);
+  return backward_impl(n, d_gout, ld_gout, d_grads, d_params, d_gx, (hipStream_t)stream);
 }
 
 extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const float* d_params, float* d_grads,
@@ -633,7 +962,7 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
     HMP_TRY(masked_ce_launch(out_ptr(n), n->out_ld, batch->n_out, n->out_dim, batch->d_labels, args->ignored_label, n->d_gout,
                              n->out_ld, d_grads + na, n->d_state, st));
   }
-  return backward_impl(n, n->d_gout, n->out_ld, d_grads, nullptr, st);
+  return backward_impl(n, n->d_gout, n->out_ld, d_grads, d_params, nullptr, st);
 }
 
 extern "C" int hmp_net_step_adam(hmp_net* n, float* d_params, const float* d_grads, float* d_m, float* d_v,
@@ -672,8 +1001,8 @@ extern "C" int hmp_net_profile_read(hmp_net* n, float* ms_sum, int32_t* launches
     float ms = 0.f;
     HMP_HIP(hipEventElapsedTime(&ms, r.a, r.b));
     if (r.cls >= 0 && r.cls < HMP_N_KCLASS) { ms_sum[r.cls] += ms; launches[r.cls] += 1; }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
   n->recs.clear();
   return HMP_OK;

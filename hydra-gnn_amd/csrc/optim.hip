@@ -141,8 +141,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ s
     float* dst = packed + S.dst + (int64_t)r * S.ld_dst;
     for (int c = threadIdx.x; c < S.ld_dst; c += blockDim.x) {
       float v = 0.f;
-      if (r < S.rows && c < S.cols) {
-        for (int q = 0; q < S.nsrc; ++q) v += params[S.src[q] + (int64_t)r * S.ld_src + c];
+      if (S.kind == PACK_SUM) {
+        if (r < S.rows && c < S.cols)
+          for (int q = 0; q < S.nsrc; ++q) v += params[S.src[q] + (int64_t)r * S.ld_src + c];
+      } else if (S.kind == PACK_HEADS) {
+        const int h = r / S.Cp, cc = r % S.Cp;
+        if (h < S.H && cc < S.C && c < S.cols) v = params[S.src[0] + (int64_t)(h * S.C + cc) * S.ld_src + c];
+      } else if (S.kind == PACK_ATTDOT) {  // row r = head
+        if (r < S.H && c < S.cols)
+          for (int cc = 0; cc < S.C; ++cc)
+            v += params[S.att + r * S.C + cc] * params[S.src[0] + (int64_t)(r * S.C + cc) * S.ld_src + c];
+      } else {  // PACK_ATTDOT_T: row r = edge-attribute dimension d, column c = head
+        if (r < S.rows && c < S.H)
+          for (int cc = 0; cc < S.C; ++cc)
+            v += params[S.att + c * S.C + cc] * params[S.src[0] + (int64_t)(c * S.C + cc) * S.ld_src + r];
       }
       dst[c] = v;
     }
@@ -162,7 +174,8 @@ int pack_launch(const PackSeg* d_segs, int n_segs, int64_t total_rows, const int
 // grad reduce: split-K slabs of the packed weight gradients -> flat gradient buffer (fixed slab order).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, int n_segs, const int64_t* __restrict__ elem_start,
-                                                          const GradReduceDyn dyn, const float* __restrict__ slabs, float* __restrict__ grads) {
+                                                          const GradReduceDyn dyn, const float* __restrict__ slabs,
+                                                          const float* __restrict__ params, float* __restrict__ grads) {
   const int64_t total = elem_start[n_segs];
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     int lo = 0, hi = n_segs - 1;
@@ -170,24 +183,57 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
       const int mid = (lo + hi + 1) >> 1;
       if (elem_start[mid] <= g) lo = mid; else hi = mid - 1;
     }
-    const GradSeg S = segs[lo];
+    const GradSeg& S = segs[lo];
     const int64_t i = g - elem_start[lo];
     const int r = (int)(i / S.cols), c = (int)(i % S.cols);
-    const int ns = dyn.n_slabs[S.slab_id];
-    const int64_t stride = dyn.slab_stride[S.slab_id];
-    const float* src = slabs + S.src + (int64_t)r * S.ld_src + c;
-    float v = 0.f;
-    for (int z = 0; z < ns; ++z) v += src[z * stride];
-    grads[S.dst + i] = v;
+    float total = 0.f;
+    for (int ti = 0; ti < S.n_terms; ++ti) {
+      const GradTerm& T = S.t[ti];
+      const int ns = dyn.n_slabs[T.slab_id];
+      const int64_t stride = dyn.slab_stride[T.slab_id];
+      const float* base = slabs + T.src;
+      float v = 0.f;
+      if (T.kind == GT_COPY) {
+        const float* src = base + (int64_t)((r / T.C) * T.Cp + (r % T.C)) * T.ld + c;
+        for (int z = 0; z < ns; ++z) v += src[z * stride];
+      } else if (T.kind == GT_ATT_OUTER) {
+        const float* src = base + (int64_t)(r / T.C) * T.ld + c;
+        float s = 0.f;
+        for (int z = 0; z < ns; ++z) s += src[z * stride];
+        v = params[T.att + r] * s;
+      } else if (T.kind == GT_ATT_DOT) {
+        const float* src = base + (int64_t)(r / T.C) * T.ld;
+        const float* w = params + T.w + (int64_t)r * T.ldw;
+        for (int f = 0; f < T.inner; ++f) {
+          float s = 0.f;
+          for (int z = 0; z < ns; ++z) s += src[z * stride + f];
+          v += s * w[f];
+        }
+      } else if (T.kind == GT_ATT_OUTER_T) {
+        const float* src = base + (int64_t)c * T.ld + (r / T.C);
+        float s = 0.f;
+        for (int z = 0; z < ns; ++z) s += src[z * stride];
+        v = params[T.att + r] * s;
+      } else {  // GT_ATT_DOT_T
+        const float* w = params + T.w + (int64_t)r * T.ldw;
+        for (int d = 0; d < T.inner; ++d) {
+          float s = 0.f;
+          for (int z = 0; z < ns; ++z) s += base[z * stride + (int64_t)d * T.ld + (r / T.C)];
+          v += s * w[d];
+        }
+      }
+      total += v * T.scale;
+    }
+    grads[S.dst + i] = total;
   }
 }
 
 int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t total_elems, const int64_t* d_elem_start, const GradReduceDyn& dyn,
-                       const float* d_slabs, float* d_grads, hipStream_t st) {
+                       const float* d_slabs, const float* d_params, float* d_grads, hipStream_t st) {
   if (n_segs == 0 || total_elems == 0) return HMP_OK;
   const int64_t want = cdiv(total_elems, 256);
   const int grid = (int)(want > 2048 ? 2048 : want);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, st, d_segs, n_segs, d_elem_start, dyn, d_slabs, d_grads);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, st, d_segs, n_segs, d_elem_start, dyn, d_slabs, d_params, d_grads);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

@@ -31,7 +31,7 @@ class Plan(C.Structure):
 class GatArgs(C.Structure):
     _fields_ = [
         ("heads", C.c_int32), ("channels", C.c_int32), ("self_loops", C.c_int32),
-        ("negative_slope", C.c_float), ("dropout_p", C.c_float),
+        ("edge_dim", C.c_int32), ("dropout_p", C.c_float),
         ("seed", C.c_uint64), ("rng_stream", C.c_uint32), ("rng_step", C.c_uint32),
     ]
 
@@ -41,6 +41,7 @@ class ConvSpec(C.Structure):
         ("kind", C.c_int32), ("edge_type", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32),
         ("f_out", C.c_int32), ("heads", C.c_int32), ("concat", C.c_int32), ("self_loops", C.c_int32),
         ("edge_dim", C.c_int32), ("fill_mean", C.c_int32), ("shared_lin", C.c_int32), ("active", C.c_int32),
+        ("att_dropout", C.c_float),
         ("w0", C.c_int64), ("w1", C.c_int64), ("w2", C.c_int64), ("a0", C.c_int64), ("a1", C.c_int64),
         ("a2", C.c_int64), ("b0", C.c_int64),
     ]
@@ -101,9 +102,9 @@ SIGNATURES = {
     "hmp_segment_mean_fwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
     "hmp_segment_mean_bwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
     "hmp_gemm_f32": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
-    "hmp_gat_fwd": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, Plan, GatArgs, _VP, _VP, _I32, _VP]),
-    "hmp_gat_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _VP, _VP, _VP, _VP, Plan, GatArgs, _VP, _VP, _I32, _VP, _VP,
-                              _VP, _VP, _VP]),
+    "hmp_gat_fwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _VP, Plan, GatArgs, _VP, _VP, _VP, _I32, _VP]),
+    "hmp_gat_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _I32, _VP, _VP, Plan, GatArgs, _VP, _VP, _VP, _VP, _VP,
+                              _VP, _I32, _VP, _I32, _VP, _I32, _VP]),
     "hmp_masked_ce": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, _VP, _I32, _VP, _VP]),
     "hmp_adam_flat": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _VP, _VP]),
     "hmp_dropout_mask": (C.c_int, [_U64, _U32, _U32, _F32, _I32, _I32, _VP, _VP]),

@@ -71,6 +71,13 @@ class NativeNet:
         # node types without features whose node COUNT matters (virtual pool targets)
         self.count_types = list(count_types)
         assert len(self.node_types) <= _lib.MAX_NODE_TYPES and len(self.edge_types) <= _lib.MAX_EDGE_TYPES
+        # edge types whose convs read edge attributes (GAT_edge) -> attribute width
+        self.edge_dims: Dict[EdgeType, int] = {}
+        for layer in layers:
+            for conv in layer.convs:
+                d = int(conv.gat.get("edge_dim", 0) or 0)
+                if d:
+                    self.edge_dims[conv.edge_type] = d
         self._mark_liveness()
         self._layout_params()
         self._handle = None
@@ -166,6 +173,7 @@ class NativeNet:
                 cs.fill_mean = int(conv.gat.get("fill_mean", 0))
                 cs.shared_lin = int(conv.gat.get("shared_lin", 0))
                 cs.active = int(conv.active)
+                cs.att_dropout = float(conv.gat.get("dropout", 0.0) or 0.0)
                 for r in ("w0", "w1", "w2", "a0", "a1", "a2", "b0"):
                     p = conv.params.get(r)
                     setattr(cs, r, self.param_offsets[id(p)] if p is not None else -1)
@@ -243,6 +251,22 @@ class NativeNet:
             else:
                 h.c.n_edges[i] = 0  # absent edge type == no edges: convs over it contribute root/bias only
             h.n_edges.append(int(h.c.n_edges[i]))
+        if self.edge_dims:
+            ea_dict = data.edge_attr_dict
+            for i, e in enumerate(self.edge_types):
+                d = self.edge_dims.get(e, 0)
+                if d == 0 or h.n_edges[i] == 0:
+                    continue
+                if e not in ea_dict:
+                    raise _lib.HydraMPError(f"edge_attr_dict[{e}] is required by the GAT_edge convs")
+                ea = ea_dict[e]
+                _require_cuda(ea, f"edge_attr_dict[{e}]")
+                if ea.dtype != torch.float32 or not ea.is_contiguous():
+                    ea = ea.to(torch.float32).contiguous()
+                if ea.dim() != 2 or ea.size(0) != h.n_edges[i] or ea.size(1) != d:
+                    raise _lib.HydraMPError(f"edge_attr_dict[{e}] must be [{h.n_edges[i]}, {d}], got {tuple(ea.shape)}")
+                h.keep.append(ea)
+                h.c.d_edge_attr[i] = ea.data_ptr()
         nt = {t: i for i, t in enumerate(self.node_types)}
         out_type = self.pool_edge_type[2] if self.pool_edge_type is not None else self.readout
         h.c.n_out = h.n_nodes[nt[out_type]]
@@ -373,10 +397,9 @@ class TrainStep:
 
     def _all_reduce(self) -> None:
         if self._world() > 1:
-            import torch.distributed as dist
+            from . import parallel
 
-            dist.all_reduce(self.grads[: self.net.n_active + 2], op=dist.ReduceOp.SUM,
-                            group=None if self.pg is True else self.pg)
+            parallel.allreduce_flat(self.grads, self.net.n_active, group=None if self.pg is True else self.pg)
 
     def _phase_a(self, h, st):
         net = self.net

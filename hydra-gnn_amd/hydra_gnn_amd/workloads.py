@@ -12,6 +12,7 @@ same graphs here and on the GPU box.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -145,14 +146,65 @@ def big_hetero_graph(n_obj: int = 1_000_000, n_rooms: int = 10_000, deg: int = 1
     return g
 
 
-def stanford_graph(npz, i: int) -> Data:
-    """Config 1 input: graph ``i`` of the committed Stanford3DSG fixture subset
-    (``tests/golden/stanford3dsg_subset.npz``; layout of reference ``data/Stanford3DSG.pkl``,
-    SURVEY Appendix B.4): room is node 0, x is ``[N, 6]`` float32."""
-    x = torch.from_numpy(npz[f"x_{i}"])
-    return Data(
-        x=x,
-        edge_index=torch.from_numpy(npz[f"edge_index_{i}"]),
-        y=torch.from_numpy(npz[f"y_{i}"]),
-        room_mask=torch.from_numpy(npz[f"room_mask_{i}"]),
-    )
+def stanford_like_graph(rng: np.random.Generator, n_nodes: Optional[int] = None) -> Data:
+    """Config 1 input: a Stanford3DSG-shaped single-room graph (room is node 0, ``x`` is
+    ``[N, 6]`` float32 = pos | size, N in 2..27, every object -> room in ONE direction, object <-> object symmetric,
+    15 room / 35 object classes).  The reference's ``data/Stanford3DSG.pkl`` itself is not used: both
+    ``torch.load(weights_only=True)`` and ``numpy.load(allow_pickle=False)`` refuse it."""
+    n = int(n_nodes if n_nodes is not None else rng.integers(2, 28))
+    x = np.concatenate([rng.normal(0, 3.0, size=(n, 3)), rng.uniform(0.1, 3.0, size=(n, 3))], 1).astype(np.float32)
+    k = n - 1
+    obj_room = np.stack([np.arange(1, n), np.zeros(k, dtype=np.int64)], 0)
+    pairs = []
+    if k >= 2:
+        iu, ju = np.triu_indices(k, 1)
+        want = min(len(iu), int(round(1.5 * k)))
+        sel = np.sort(rng.choice(len(iu), size=want, replace=False))
+        pairs = np.stack([iu[sel] + 1, ju[sel] + 1], 1)
+    oo = _sym_edges(np.asarray(pairs, dtype=np.int64).reshape(-1, 2))
+    y = np.concatenate([rng.integers(0, 15, size=1), rng.integers(0, 35, size=k)]).astype(np.int64)
+    mask = np.zeros(n, dtype=bool)
+    mask[0] = True
+    return Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.concatenate([obj_room, oo], 1).astype(np.int64)),
+                y=torch.from_numpy(y), room_mask=torch.from_numpy(mask))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4: H-tree (Neural-Tree) batches from the committed topology fixture (tests/golden/htree_topologies.npz, made by
+# tests/golden/make_htree_fixture.py with the reference's junction-tree code)
+# ---------------------------------------------------------------------------------------------------------------------
+from .data import HTREE_EDGE_TYPES, HTREE_NODE_TYPES  # noqa: E402
+
+HTREE_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
+                             "htree_topologies.npz")
+
+
+def htree_graph(npz, gi: int, rng: np.random.Generator) -> HeteroData:
+    """One H-tree HeteroData (layout SURVEY Appendix B.2: object 306-d, room / object-room / room-room 6-d, ``room_virtual``
+    carries ``num_nodes`` and ``y``; 10 message-passing edge types + the ``r_to_rv`` pool edges)."""
+    counts = npz[f"g{gi}_counts"]
+    n_rooms = int(npz[f"g{gi}_n_rooms"])
+    g = HeteroData()
+    dims = {"object": 306, "room": 6, "object-room": 6, "room-room": 6}
+    for t, c in zip(HTREE_NODE_TYPES, counts):
+        pos = rng.normal(0.0, 5.0, size=(int(c), 3))
+        rest = rng.uniform(0.1, 2.0, size=(int(c), 3)) if t in ("object", "room") else np.zeros((int(c), 3))
+        cols = [pos, rest]
+        if dims[t] > 6:
+            cols.append(rng.normal(0.0, 0.15, size=(int(c), dims[t] - 6)))
+        g[t].x = torch.from_numpy(np.concatenate(cols, 1).astype(np.float32))
+    for k, et in enumerate(HTREE_EDGE_TYPES):
+        g[et].edge_index = torch.from_numpy(npz[f"g{gi}_e{k}"].astype(np.int64).reshape(2, -1))
+    room_orig = npz[f"g{gi}_room_orig"].astype(np.int64)
+    g["room", "r_to_rv", "room_virtual"].edge_index = torch.from_numpy(np.stack([np.arange(len(room_orig)), room_orig], 0))
+    g["room_virtual"].num_nodes = n_rooms
+    g["room_virtual"].y = torch.from_numpy(rng.integers(0, NUM_ROOM_LABELS, size=n_rooms).astype(np.int64))
+    return g
+
+
+def htree_batch(batch_size: int = 128, seed: int = BASE_SEED + 4, fixture: Optional[str] = None) -> HeteroData:
+    """Config 4 (``seed = BASE_SEED + 4``): the fixture's topologies tiled to ``batch_size`` graphs, fresh features/labels."""
+    npz = np.load(fixture or HTREE_FIXTURE)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(npz["n_graphs"])
+    return collate([htree_graph(npz, i % n, rng) for i in range(batch_size)])

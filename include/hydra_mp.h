@@ -92,33 +92,41 @@ int hmp_gemm_f32(const float* d_a, int32_t lda, int32_t trans_a, const float* d_
                  float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * 4. K3 -- GAT edge softmax + weighted aggregation, one wavefront group per destination row.
- *    Replaces [PyG] GATConv.edge_update + softmax + message/aggregate.
- *    h_src [n_src, H*C] (ld = ldh), a_src [n_src, H], a_dst [n_dst, H]; optional per-edge logit term
- *    a_edge [E, H] in ORIGINAL edge order (NULL = none).  With self_loops != 0 entries with
- *    col == row are skipped and one loop edge i->i is appended per row i < min(n_src, n_dst)
- *    (its a_edge term is d_a_loop [n, H] or 0 when NULL).
- *    alpha (post-softmax, pre-dropout) is written in CSR order [E + n_loop, H] for the backward.
- *    out [n_dst, H*C] = sum_k dropout(alpha_k) * h_src[col_k]   (no bias / head-mean here).
+ * 4. K3 -- GAT edge softmax + weighted aggregation, one row group of lanes per destination row.
+ *    Replaces [PyG] GATConv.edge_update + softmax + message/aggregate for ONE conv.
+ *    Inputs: h_src [n_src, H*Cp] projected source rows, head h at columns h*Cp (Cp = channels rounded up to 4);
+ *    a_src [n_src, >=H] (ld lda_src), a_dst [n_dst, >=H] (ld lda_dst): attention logits halves;
+ *    optional edge term <edge_attr[e, 0:edge_dim], v_edge[0:edge_dim, h]> with v_edge [edge_dim][8]
+ *    (edge_attr in ORIGINAL edge order; NULL / edge_dim 0 = none).
+ *    e_k = leaky_relu(a_src[col_k,h] + a_dst[i,h] + edge term, 0.2); alpha = softmax over the row
+ *    (max-subtracted, denominator + 1e-16); out[i, h*C + c] = sum_k dropout(alpha_k,h) * h_src[col_k, h*Cp + c].
+ *    With self_loops != 0 entries with col == row are skipped and one loop i->i (edge term 0) is appended per
+ *    row i < min(n_src, n_dst).  The softmax is computed online; the per-row running max and denominator are
+ *    written to smax / sden [n_dst, 8] for the backward (alpha is recomputed there, never stored in forward).
+ *    These two unit entry points upload a small descriptor and SYNCHRONISE the stream (test / integration use;
+ *    the network executor below drives the same kernels without synchronising).
  * ------------------------------------------------------------------------------------------- */
 typedef struct hmp_gat_args {
-  int32_t heads, channels;
+  int32_t heads, channels;   /* H <= 8, C <= 256 */
   int32_t self_loops;
-  float negative_slope;
+  int32_t edge_dim;          /* 0..4 */
   float dropout_p;           /* attention dropout; 0 = off */
-  uint64_t seed;             /* dropout RNG (Philox4x32-10) */
-  uint32_t rng_stream, rng_step;
+  uint64_t seed;             /* dropout RNG (Philox4x32-10): element (pos, h) of an [E + n_loop, 8] tensor, */
+  uint32_t rng_stream, rng_step; /* pos = CSR position of the edge, loops at E + i (see hmp_dropout_mask) */
 } hmp_gat_args;
 
-int hmp_gat_fwd(const float* d_h_src, int32_t ldh, const float* d_a_src, const float* d_a_dst, const float* d_a_edge,
-                const float* d_a_loop, hmp_plan plan, hmp_gat_args args, float* d_alpha, float* d_out, int32_t ldo,
-                void* stream);
-/* grads: g_h_src [n_src, H*C], g_a_src [n_src, H], g_a_dst [n_dst, H], g_a_edge [E, H] (original edge
- * order, may be NULL), g_a_loop [n, H] (may be NULL).  d_dlogit is scratch [E + n_loop, H]. */
-int hmp_gat_bwd(const float* d_gout, int32_t ldo, const float* d_h_src, int32_t ldh, const float* d_a_src,
-                const float* d_a_dst, const float* d_a_edge, const float* d_a_loop, const float* d_alpha, hmp_plan plan,
-                hmp_gat_args args, float* d_dlogit, float* d_g_h_src, int32_t ldgh, float* d_g_a_src, float* d_g_a_dst,
-                float* d_g_a_edge, float* d_g_a_loop, void* stream);
+int hmp_gat_fwd(const float* d_h_src, int32_t ldh, const float* d_a_src, int32_t lda_src, const float* d_a_dst,
+                int32_t lda_dst, const float* d_edge_attr, const float* d_v_edge, hmp_plan plan, hmp_gat_args args,
+                float* d_smax, float* d_sden, float* d_out, int32_t ldo, void* stream);
+/* d_gout [n_dst, H*C].  Outputs: g_h_src [n_src, H*Cp] (ld ldgh), g_a_src [n_src, >=H] (ld ldgas), g_a_dst
+ * [n_dst, >=H] (ld ldgad); d_alpha_drop / d_dlogit [E + n_loop, 8] receive alpha after dropout and d loss / d raw
+ * logit per CSR position; d_dlogit_orig [E, 8] (may be NULL) the same in original edge order, so that
+ * d v_edge = edge_attr^T * dlogit_orig. */
+int hmp_gat_bwd(const float* d_gout, int32_t ldg, const float* d_h_src, int32_t ldh, const float* d_a_src, int32_t lda_src,
+                const float* d_a_dst, int32_t lda_dst, const float* d_edge_attr, const float* d_v_edge, hmp_plan plan,
+                hmp_gat_args args, const float* d_smax, const float* d_sden, float* d_alpha_drop, float* d_dlogit,
+                float* d_dlogit_orig, float* d_g_h_src, int32_t ldgh, float* d_g_a_src, int32_t ldgas, float* d_g_a_dst,
+                int32_t ldgad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 5. loss + optimiser
@@ -163,6 +171,7 @@ typedef struct hmp_conv_spec {
   int32_t fill_mean;  /* GAT_edge self-loop attr: 1 = per-destination mean, 0 = zeros */
   int32_t shared_lin; /* GAT built from an int in_channels: lin_dst IS lin_src */
   int32_t active;     /* 0 = output never reaches the loss: skipped in forward and backward */
+  float att_dropout;  /* GAT: dropout on the attention coefficients (GATConv(dropout=p)), training only */
   /* offsets (floats) into the flat parameter buffer, -1 = absent.
    * SAGE: w0 = lin_l.weight [f_out, f_src], b0 = lin_l.bias [f_out], w1 = lin_r.weight [f_out, f_dst]
    * GAT : w0 = lin_src.weight [H*C, f_src], w1 = lin_dst.weight [H*C, f_dst], a0 = att_src [H*C],

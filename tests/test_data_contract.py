@@ -1,0 +1,127 @@
+"""CPU tests of the input contract: the reference's own known answers for ``fill_missing_edge_index``
+(``tests/test_mp3d_dataset.py:143-180`` -- the only tensor-level vectors the reference's tests hold for this path),
+PyG ``Batch.from_data_list`` collation offsets, ``compute_relative_pos``
+(``src/hydra_gnn/mp3d_dataset.py:298-319``) and the committed H-tree topology fixture."""
+import os
+
+import numpy as np
+import torch
+
+from hydra_gnn_amd import workloads
+from hydra_gnn_amd.data import (EDGE_TYPES, HTREE_EDGE_TYPES, HeteroData, collate, compute_relative_pos,
+                                fill_missing_edge_index)
+
+
+def test_fill_missing_edge_index_reference_case_1_room():
+    # reference tests/test_mp3d_dataset.py:145-161
+    data = HeteroData()
+    data["rooms"].x = torch.rand((1, 6))
+    data["objects"].x = torch.rand((3, 306))
+    object_edge = torch.tensor([[0, 1, 1, 2, 2, 0], [1, 0, 2, 1, 0, 2]])
+    room_object_edge = torch.tensor([[0, 0, 0], [0, 1, 2]])
+    data["objects", "objects_to_objects", "objects"].edge_index = object_edge
+    data["rooms", "rooms_to_objects", "objects"].edge_index = room_object_edge
+    fill_missing_edge_index(data, edge_types=EDGE_TYPES)
+    assert ("rooms", "rooms_to_rooms", "rooms") in data.edge_index_dict
+    assert data[("rooms", "rooms_to_rooms", "rooms")].num_edges == 0
+    assert data[("rooms", "rooms_to_rooms", "rooms")].edge_index.dtype == torch.int64
+    assert ("objects", "objects_to_rooms", "rooms") in data.edge_index_dict
+    assert torch.all(data[("objects", "objects_to_rooms", "rooms")].edge_index == room_object_edge.flip([0]))
+
+
+def test_fill_missing_edge_index_reference_case_2_rooms():
+    # reference tests/test_mp3d_dataset.py:163-180
+    data = HeteroData()
+    data["rooms"].x = torch.rand((2, 6))
+    data["objects"].x = torch.rand((4, 306))
+    room_edge = torch.tensor([[0, 1], [1, 0]])
+    object_edge = torch.tensor([[0, 1, 1, 2, 2, 0], [1, 0, 2, 1, 0, 2]])
+    room_object_edge = torch.tensor([[0, 0, 0, 1], [0, 1, 2, 3]])
+    data["rooms", "rooms_to_rooms", "rooms"].edge_index = room_edge
+    data["objects", "objects_to_objects", "objects"].edge_index = object_edge
+    data["rooms", "rooms_to_objects", "objects"].edge_index = room_object_edge
+    fill_missing_edge_index(data, edge_types=EDGE_TYPES)
+    assert data[("rooms", "rooms_to_rooms", "rooms")].num_edges == 2
+    assert torch.all(data[("objects", "objects_to_rooms", "rooms")].edge_index == room_object_edge.flip([0]))
+
+
+def test_fill_missing_inter_type_without_reverse_is_empty():
+    data = HeteroData()
+    data["rooms"].x = torch.rand((1, 6))
+    data["objects"].x = torch.rand((2, 306))
+    fill_missing_edge_index(data, edge_types=EDGE_TYPES)
+    for et in EDGE_TYPES:
+        assert data[et].edge_index.shape == (2, 0)
+
+
+def test_collate_offsets_follow_source_and_destination_types():
+    g1 = workloads.mp3d_like_graph(np.random.default_rng(0))
+    g2 = workloads.mp3d_like_graph(np.random.default_rng(1))
+    b = collate([g1, g2])
+    no1, nr1 = g1["objects"].num_nodes, g1["rooms"].num_nodes
+    assert b["objects"].num_nodes == no1 + g2["objects"].num_nodes
+    assert torch.equal(b["objects"].x[no1:], g2["objects"].x)
+    et = ("objects", "objects_to_rooms", "rooms")
+    e1 = g1[et].num_edges
+    assert torch.equal(b[et].edge_index[:, :e1], g1[et].edge_index)
+    assert torch.equal(b[et].edge_index[0, e1:], g2[et].edge_index[0] + no1)   # source rows offset by #objects
+    assert torch.equal(b[et].edge_index[1, e1:], g2[et].edge_index[1] + nr1)   # destination rows offset by #rooms
+    assert torch.equal(b["rooms"].ptr, torch.tensor([0, nr1, nr1 + g2["rooms"].num_nodes]))
+    assert b.num_graphs == 2
+    assert torch.equal(b["rooms"].y, torch.cat([g1["rooms"].y, g2["rooms"].y]))
+
+
+def test_compute_relative_pos():
+    g = workloads.mp3d_like_graph(np.random.default_rng(2))
+    pos_o, pos_r = g["objects"].pos.clone(), g["rooms"].pos.clone()
+    x_o = g["objects"].x.clone()
+    compute_relative_pos(g)
+    assert g["objects"].x.shape[1] == 303 and g["rooms"].x.shape[1] == 3
+    assert torch.equal(g["objects"].x, x_o[:, 3:])
+    ei = g["objects", "objects_to_rooms", "rooms"].edge_index
+    assert torch.equal(g["objects", "objects_to_rooms", "rooms"].edge_attr, pos_r[ei[1]] - pos_o[ei[0]])
+
+
+def test_config2_workload_statistics():
+    b = workloads.config2_batch(32)
+    n_o, n_r = b["objects"].num_nodes, b["rooms"].num_nodes
+    assert b["objects"].x.shape == (n_o, 306) and b["rooms"].x.shape == (n_r, 6)
+    assert 32 * 2 <= n_r <= 32 * 12
+    oo = b["objects", "objects_to_objects", "objects"].edge_index
+    assert abs(oo.shape[1] / n_o - 6.0) < 1.0           # mean in-degree ~6 (fixture graph: 5.74)
+    key = lambda e: set(map(tuple, e.t().tolist()))
+    assert key(oo) == key(oo.flip([0]))                 # stored in both directions
+    ro = b["rooms", "rooms_to_objects", "objects"].edge_index
+    assert ro.shape[1] == n_o and torch.equal(torch.sort(ro[1]).values, torch.arange(n_o))
+    assert torch.equal(b["objects", "objects_to_rooms", "rooms"].edge_index, ro.flip([0]))
+    assert int(b["rooms"].y.max()) <= 25
+    # same seed -> same batch (what the GPU box regenerates)
+    b2 = workloads.config2_batch(32)
+    assert torch.equal(b2["objects"].x, b["objects"].x) and torch.equal(b2["rooms"].y, b["rooms"].y)
+
+
+def test_htree_fixture_is_consistent():
+    assert os.path.exists(workloads.HTREE_FIXTURE)
+    npz = np.load(workloads.HTREE_FIXTURE)
+    n = int(npz["n_graphs"])
+    assert n >= 4
+    for gi in range(n):
+        counts = npz[f"g{gi}_counts"]
+        src_t = {"object": 0, "room": 1, "object-room": 2, "room-room": 3}
+        for k, (s, _, t) in enumerate(HTREE_EDGE_TYPES):
+            e = npz[f"g{gi}_e{k}"].reshape(2, -1)
+            if e.shape[1]:
+                assert e[0].max() < counts[src_t[s]] and e[1].max() < counts[src_t[t]] and e.min() >= 0
+        # every room leaf is a copy of an original room; every original room has at least one leaf
+        ro = npz[f"g{gi}_room_orig"]
+        assert len(ro) == counts[1] and set(ro.tolist()) == set(range(int(npz[f"g{gi}_n_rooms"])))
+        oo = npz[f"g{gi}_object_orig"]
+        assert set(oo.tolist()) == set(range(int(npz[f"g{gi}_n_objects"])))
+        # leaf <-> clique relations are stored in both directions
+        a = npz[f"g{gi}_e0"].reshape(2, -1)
+        b = npz[f"g{gi}_e1"].reshape(2, -1)
+        assert set(map(tuple, a.T.tolist())) == set(map(tuple, b[::-1].T.tolist()))
+    batch = workloads.htree_batch(4, seed=1)
+    assert batch["room_virtual"].num_nodes == batch["room_virtual"].y.numel()
+    pool = batch["room", "r_to_rv", "room_virtual"].edge_index
+    assert int(pool[1].max()) < batch["room_virtual"].num_nodes and pool.shape[1] == batch["room"].num_nodes

