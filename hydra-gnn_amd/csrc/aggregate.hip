@@ -75,15 +75,49 @@ __device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __r
 }
 
 // sum_k g[tcol[k]][c..] / max(deg(tcol[k]),1)  (backward of the mean: every edge carries 1/deg(dst))
+// `degf` (float max(deg,1) per destination, written by the plan) removes the two dependent rowptr loads per edge;
+// four edges are in flight at a time (ids, then degrees + rows, then the ordered adds).
 template <int GS, int NV, int VEC>
 __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* __restrict__ g, int ld, const int* __restrict__ tcol,
-                                             const int* __restrict__ rowptr, int mean, int b, int e, int c0, int F) {
-  for (int k = b; k < e; ++k) {
+                                             const int* __restrict__ rowptr, const float* __restrict__ degf, int mean, int b, int e,
+                                             int c0, int F) {
+  int k = b;
+  if (degf != nullptr || !mean) {
+    for (; k + 4 <= e; k += 4) {
+      const int i0 = tcol[k], i1 = tcol[k + 1], i2 = tcol[k + 2], i3 = tcol[k + 3];
+      float d0 = 1.f, d1 = 1.f, d2 = 1.f, d3 = 1.f;
+      if (mean) { d0 = degf[i0]; d1 = degf[i1]; d2 = degf[i2]; d3 = degf[i3]; }
+      Acc<VEC> v0[NV], v1[NV], v2[NV], v3[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c = c0 + q * GS * VEC;
+        if (c < F) {
+          v0[q].load(g + (int64_t)i0 * ld + c);
+          v1[q].load(g + (int64_t)i1 * ld + c);
+          v2[q].load(g + (int64_t)i2 * ld + c);
+          v3[q].load(g + (int64_t)i3 * ld + c);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c = c0 + q * GS * VEC;
+        if (c < F) {
+          if (mean) { acc[q].add_div(v0[q], d0); acc[q].add_div(v1[q], d1); acc[q].add_div(v2[q], d2); acc[q].add_div(v3[q], d3); }
+          else { acc[q].add(v0[q]); acc[q].add(v1[q]); acc[q].add(v2[q]); acc[q].add(v3[q]); }
+        }
+      }
+    }
+  }
+  for (; k < e; ++k) {
     const int i = tcol[k];
     float d = 1.f;
     if (mean) {
-      const int deg = rowptr[i + 1] - rowptr[i];
-      d = (float)(deg > 1 ? deg : 1);
+      if (degf) {
+        d = degf[i];
+      } else {
+        const int deg = rowptr[i + 1] - rowptr[i];
+        d = (float)(deg > 1 ? deg : 1);
+      }
     }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
@@ -129,7 +163,7 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
   Acc<VEC> acc[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) acc[q].zero();
-  gather_sum_w<GS, NV, VEC>(acc, g, ldg, t_col, rowptr, 1, t_rowptr[row], t_rowptr[row + 1], c0, F);
+  gather_sum_w<GS, NV, VEC>(acc, g, ldg, t_col, rowptr, nullptr, 1, t_rowptr[row], t_rowptr[row + 1], c0, F);
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c = c0 + q * GS * VEC;
@@ -205,7 +239,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
     Acc<VEC> acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q].zero();
-    gather_sum_w<GS, NV, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, a.mean, O.t_rowptr[row], O.t_rowptr[row + 1], c0, O.F);
+    gather_sum_w<GS, NV, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, O.t_rowptr[row], O.t_rowptr[row + 1], c0, O.F);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c = c0 + q * GS * VEC;

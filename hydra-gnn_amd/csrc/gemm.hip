@@ -5,12 +5,15 @@
 // tall-skinny problems (M = nodes: 10^2..10^6, N,K = feature widths: 6..512), and several of them per
 // layer (one per node type), so the kernel is GROUPED: one launch walks a table of problems.
 //
-// Block = 4 wavefronts.  Tile shapes (BM x BN): 64x64 (2x2 waves), or 32x32 with the 4 waves splitting
-// the K range of each staged tile (small problems: 4x the workgroups, each 4x shorter; partial
-// accumulators are summed through LDS in a fixed order, so results are run-to-run identical).
-// Operands are staged global -> registers -> LDS in [k][m] / [k][n] order, which makes every MFMA
-// operand fetch a conflict-free ds_read_b32 (lanes 0-31 read 32 consecutive floats of one k row, lanes
-// 32-63 the next k row); the next tile's global loads are issued before the current tile's MFMAs.
+// Block = 4 wavefronts.  Two shapes:
+//   <2,2,32>  64x64 tile, 2x2 waves, K stage of 32: throughput shape for big problems (many blocks per CU hide latency).
+//   <1,1,128> 32x32 tile, the 4 waves split the K range of each staged tile (partials summed through LDS in a fixed
+//             order => run-to-run identical), K stage of 128: LATENCY shape for the small problems of MP3D batches --
+//             4x the workgroups, and each barrier interval carries 8 independent 16-byte loads per lane and 16 MFMAs
+//             per wave instead of 2 and 4, so a K = 306 projection is 3 load round trips deep instead of 10.
+// Operands are staged global -> registers -> LDS in [k][m] / [k][n] order, which makes every MFMA operand fetch a
+// conflict-free ds_read_b32 (lanes 0-31 read 32 consecutive floats of one k row, lanes 32-63 the next k row); the
+// next stage's global loads are issued before the current stage's MFMAs.
 //
 // Forms: NT (x * W^T, nn.Linear), NN (dZ * W, input gradient, optional activation-derivative epilogue),
 // TN with split-K over node chunks (dZ^T * [x | 1], weight + bias gradient; slabs are reduced later).
@@ -20,21 +23,20 @@ namespace hmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-
-// Loads a (ROWS x BK) tile into registers; logical element (r, k).
+// A (ROWS x BK) tile in registers; logical element (r, k).
 //  kcontig = 1: memory is [r][k] (k contiguous)  -> per thread NV float4 along k
 //  kcontig = 0: memory is [k][r] (r contiguous)  -> per thread NV float4 along r
-template <int ROWS>
+template <int ROWS, int BK>
 struct TileRegs {
   static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
   float4 v[NV];
 };
 
-template <int ROWS>
-__device__ __forceinline__ void tile_load(TileRegs<ROWS>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
-                                          int R, int n_real, int aug, int k0, int kend, bool vec_ok) {
-  constexpr int NV = TileRegs<ROWS>::NV;
+// vec: 4 = 16-byte loads, 2 = 8-byte loads (rows only 8-byte aligned, e.g. ld = 306), 1 = scalar
+template <int ROWS, int BK>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
+                                          int R, int n_real, int aug, int k0, int kend, int vec) {
+  constexpr int NV = TileRegs<ROWS, BK>::NV;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -43,12 +45,16 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS>& t, const float* __rest
     if (kcontig) {
       const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
       const int gr = r0 + r, gk = k0 + k4;
-      if (gr < R) {
+      if (gr < R && gk < kend) {
         const float* src = p + (int64_t)gr * ld + gk;
-        if (vec_ok && gk + 3 < kend) {
+        if (vec == 4 && gk + 3 < kend) {
           val = *reinterpret_cast<const float4*>(src);
+        } else if (vec == 2 && gk + 3 < kend) {
+          const float2 a = *reinterpret_cast<const float2*>(src);
+          const float2 b = *reinterpret_cast<const float2*>(src + 2);
+          val = make_float4(a.x, a.y, b.x, b.y);
         } else {
-          if (gk + 0 < kend) val.x = src[0];
+          val.x = src[0];
           if (gk + 1 < kend) val.y = src[1];
           if (gk + 2 < kend) val.z = src[2];
           if (gk + 3 < kend) val.w = src[3];
@@ -59,8 +65,12 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS>& t, const float* __rest
       const int gk = k0 + k, gr = r0 + r4;
       if (gk < kend) {
         const float* src = p + (int64_t)gk * ld + gr;
-        if (vec_ok && gr + 3 < n_real) {
+        if (vec == 4 && gr + 3 < n_real) {
           val = *reinterpret_cast<const float4*>(src);
+        } else if (vec == 2 && gr + 3 < n_real) {
+          const float2 a = *reinterpret_cast<const float2*>(src);
+          const float2 b = *reinterpret_cast<const float2*>(src + 2);
+          val = make_float4(a.x, a.y, b.x, b.y);
         } else {
           float e[4];
 #pragma unroll
@@ -77,9 +87,9 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS>& t, const float* __rest
 }
 
 // LDS image is [k][LD] with LD = ROWS + 4
-template <int ROWS>
-__device__ __forceinline__ void tile_store(const TileRegs<ROWS>& t, float* __restrict__ s, int kcontig) {
-  constexpr int NV = TileRegs<ROWS>::NV;
+template <int ROWS, int BK>
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& t, float* __restrict__ s, int kcontig) {
+  constexpr int NV = TileRegs<ROWS, BK>::NV;
   constexpr int LD = ROWS + 4;
   const int tid = threadIdx.x;
 #pragma unroll
@@ -106,7 +116,15 @@ __device__ __forceinline__ float act_mask_factor(float h, int act, bool keep, fl
   return scale;
 }
 
-template <int WM, int WN>
+__device__ __forceinline__ int vec_mode(const float* p, int ld, bool k_ok) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if (!k_ok) return 1;
+  if ((ld & 3) == 0 && (a & 15) == 0) return 4;
+  if ((ld & 1) == 0 && (a & 7) == 0) return 2;
+  return 1;
+}
+
+template <int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   constexpr int BM = 32 * WM, BN = 32 * WN, KW = 4 / (WM * WN);
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -129,8 +147,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
 
   const int a_kcontig = P.trans_a ? 0 : 1;
   const int b_kcontig = P.trans_b ? 1 : 0;
-  const bool a_vec = ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && (a_kcontig ? (kbeg & 3) == 0 : true);
-  const bool b_vec = ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && (b_kcontig ? (kbeg & 3) == 0 : true);
+  // kbeg is a multiple of BK (>= 32), so k offsets keep the row alignment class
+  const int a_vec = vec_mode(P.A, P.lda, true);
+  const int b_vec = vec_mode(P.B, P.ldb, true);
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w % WM, wn = (w / WM) % WN, kw = w / (WM * WN);
@@ -139,28 +158,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  TileRegs<BM> ra;
-  TileRegs<BN> rb;
-  // for A the "row" dimension is M (bounds M, no aug); for B it is N (n_real real columns, optional ones column)
-  tile_load<BM>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kbeg, kend, a_vec);
-  tile_load<BN>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kbeg, kend, b_vec);
+  TileRegs<BM, BK> ra;
+  TileRegs<BN, BK> rb;
+  // for A the "row" dimension is M; for B it is N (n_real real columns, optional virtual ones column)
+  tile_load<BM, BK>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kbeg, kend, a_vec);
+  tile_load<BN, BK>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kbeg, kend, b_vec);
 
   for (int kt = kbeg; kt < kend; kt += BK) {
-    tile_store<BM>(ra, As, a_kcontig);
-    tile_store<BN>(rb, Bs, b_kcontig);
+    tile_store<BM, BK>(ra, As, a_kcontig);
+    tile_store<BN, BK>(rb, Bs, b_kcontig);
     __syncthreads();
     if (kt + BK < kend) {
-      tile_load<BM>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kt + BK, kend, a_vec);
-      tile_load<BN>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kt + BK, kend, b_vec);
+      tile_load<BM, BK>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kt + BK, kend, a_vec);
+      tile_load<BN, BK>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kt + BK, kend, b_vec);
     }
     constexpr int KS = BK / KW;
+    const int klen = min(BK, kend - kt);  // tail stage: skip the k rows that are all zero
     const float* ap = As + (kw * KS + (lane >> 5)) * LDA + wm * 32 + (lane & 31);
     const float* bp = Bs + (kw * KS + (lane >> 5)) * LDB + wn * 32 + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < KS; kk += 2) {
-      const float a = ap[kk * LDA];
-      const float b = bp[kk * LDB];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      if (kw * KS + kk < klen) {
+        const float a = ap[kk * LDA];
+        const float b = bp[kk * LDB];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -186,6 +208,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   float* C = P.C + (int64_t)z * P.slab_stride;
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= P.N) return;
+  DropCfg dcfg;
+  if (P.epi == EPI_ACTMASK && P.drop_on) dcfg = drop_resolve(P.drop);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -197,9 +221,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
       float scale = 1.f;
       if (P.drop_on) {
         bool k4[4];
-        drop_keep4(drop_resolve(P.drop), (uint32_t)row * (uint32_t)(P.ldh >> 2) + (uint32_t)(col >> 2), k4);
+        drop_keep4(dcfg, (uint32_t)row * (uint32_t)(P.ldh >> 2) + (uint32_t)(col >> 2), k4);
         keep = k4[col & 3];
-        scale = P.drop.scale;
+        scale = dcfg.scale;
       }
       v *= act_mask_factor(h, P.act, keep, scale);
     }
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int BK>
 static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   int start = 0;
@@ -218,9 +242,9 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
     int tiles = p.tiles_m * p.tiles_n;
     int ks = 1;
     if (want_split && tiles > 0) {
-      // aim at ~1024 workgroups overall; every slab gets >= 2 K tiles
+      // aim at ~1024 workgroups overall; every slab gets >= 1 full K stage
       ks = 1024 / (tiles * gb.n);
-      int max_by_k = cdiv(p.K, 2 * BK);
+      int max_by_k = cdiv(p.K, BK);
       if (ks > max_by_k) ks = max_by_k;
       if (ks > max_slabs) ks = max_slabs;
       if (ks < 1) ks = 1;
@@ -235,23 +259,22 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
   }
   gb.total_tiles = start;
   if (start == 0) return HMP_OK;
-  hipLaunchKernelGGL((gemm_kernel<WM, WN>), dim3(start), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL((gemm_kernel<WM, WN, BK>), dim3(start), dim3(256), 0, st, gb);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
 
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm: %d problems", gb.n);
-  // drop empty problems (M, N or K = 0): with K == 0 the output must still be zero-filled
   int64_t tiles64 = 0;
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative size");
     tiles64 += (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
   }
-  // big problems: 64x64 tiles; small ones: 32x32 tiles with in-block K split
-  if (tiles64 >= 1024) return launch_cfg<2, 2>(gb, want_split, max_slabs, st);
-  return launch_cfg<1, 1>(gb, want_split, max_slabs, st);
+  // big problems: 64x64 tiles; small ones: 32x32 tiles with in-block K split and deep K stages
+  if (tiles64 >= 1024) return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
+  return launch_cfg<1, 1, 128>(gb, want_split, max_slabs, st);
 }
 
 }  // namespace hmp

@@ -46,12 +46,15 @@ struct PlanJob {
   int64_t E;
   int n_src, n_dst;
   int *rowptr, *col, *eid, *t_rowptr, *t_col, *t_pos;
+  float* degf;  // optional [n_dst]: max(in-degree, 1) as float
   // scratch
-  int *cnt_in, *cnt_out, *cur_in, *cur_out;  // zeroed before the launch (one contiguous block)
+  int *cnt_in, *cnt_out, *cur_in, *cur_out;  // must be zero on entry (one contiguous block); left zero on exit
   int *tmp_in, *tmp_out, *t_eid, *pos_of_eid;
 };
 struct PlanBatch {
   int n;
+  int need_tpos;   // build t_pos (only GAT's source-major backward reads it)
+  int clear_first; // memset the counters before the launch (caller-provided scratch of unknown content)
   int64_t edge_start[HMP_MAX_EDGE_TYPES + 1];
   int64_t row_start[2 * HMP_MAX_EDGE_TYPES + 1];  // rows of (job, dir): dir 0 = by dst, 1 = by src
   PlanJob j[HMP_MAX_EDGE_TYPES];
@@ -97,6 +100,7 @@ struct TAggOut {
   const int* t_rowptr;
   const int* t_col;
   const int* rowptr;  // forward CSR rowptr of the same edge type (for 1/deg of the destination)
+  const float* degf;  // max(deg,1) per destination as float (plan by-product), null: derive from rowptr
   const float* g;     // gradient rows of the destination type
   int ldg, coff, F;
 };
@@ -136,8 +140,10 @@ struct PackSeg {
   int64_t att;      // PACK_ATTDOT*: float offset of the attention vector [H*C]
   int64_t src[AGG_MAX_IN];  // float offsets into the flat parameter buffer (summed)
 };
-int pack_launch(const PackSeg* d_segs, int n_segs, int64_t total_rows, const int64_t* d_row_start, const float* d_params,
-                float* d_packed, hipStream_t st);
+struct NetState;
+// step_state != null: block (0,0) increments step_state->step (the fused step starts with the pack)
+int pack_launch(const PackSeg* d_segs, int n_segs, int max_rows_pad, const float* d_params, float* d_packed, NetState* step_state,
+                hipStream_t st);
 
 // A parameter gradient element (r, c) is the sum of up to 3 terms read from split-K slabs S (summed over slabs):
 //  GT_COPY       S[(r/C*Cp + r%C) * ld + c]                         (rows of the stacked operand; C = Cp: identity)
@@ -244,22 +250,25 @@ int gat_fwd_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, 
 int gat_bwd1_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
 int gat_bwd2_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
 
-int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t total_elems, const int64_t* d_elem_start,
-                       const GradReduceDyn& dyn, const float* d_slabs, const float* d_params, float* d_grads, hipStream_t st);
+// row_lv != null: block (0,0) also sums the per-row {loss, valid} pairs (masked_ce_rows_launch) into out2 / state
+int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t max_elems, const GradReduceDyn& dyn, const float* d_slabs,
+                       const float* d_params, float* d_grads, const float* row_lv, int n_lv_rows, float* out2, NetState* state,
+                       hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // loss / adam
 // ---------------------------------------------------------------------------------------------
 struct NetState {  // device resident
-  int step;        // completed optimiser steps
+  int step;        // fused steps started so far (bumped by the pack kernel at the head of every step)
   int status;      // bit 0: edge endpoint out of range, bit 1: label out of range
   float loss_sum, count;
 };
 int masked_ce_launch(const float* logits, int ldl, int n_rows, int n_classes, const int64_t* labels, int64_t ignored,
                      float* grad, int ldg, float* out2, NetState* state_or_null, hipStream_t st);
-// step_dev != null: t = *step_dev + 1 is read on the device (graph replay); else t = step_host
+int masked_ce_rows_launch(const float* logits, int ldl, int n_rows, int n_classes, const int64_t* labels, int64_t ignored,
+                          float* grad, int ldg, float* row_lv, NetState* state, hipStream_t st);
+// step_dev != null: t = *step_dev is read on the device (graph replay); else t = step_host
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                 int step_host, const int* step_dev, const float* d_count, hipStream_t st);
-int step_increment_launch(NetState* state, hipStream_t st);
 
 }  // namespace hmp

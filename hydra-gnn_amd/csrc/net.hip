@@ -17,6 +17,7 @@
 // (and likewise a_d, and the edge term <lin_edge(e), att_edge> = e * V_edge), so the stacked operand of a source
 // type also carries the H rows of V_src^T (and of V_dst^T for the destination role): ONE projection per node
 // type yields h_s, a_s and a_d; the chain rule back to lin/att runs in the gradient un-pack kernel.
+#include <cstdlib>
 #include <vector>
 
 #include "kernels.h"
@@ -82,6 +83,11 @@ struct hmp_net {
   int64_t* d_grad_elem_start = nullptr;
   int n_grad = 0;
   int64_t grad_elems = 0;
+  int max_pack_rows = 0;
+  int64_t max_grad_elems = 0;
+  float* degf[HMP_MAX_EDGE_TYPES];  // max(in-degree,1) per destination node, by-product of the plan
+  float* d_row_lv = nullptr;        // per output row {loss, valid} of the fused step's loss kernel
+  bool fin_loss = false;            // the next gradient un-pack also finalises {loss_sum, count}
 
   // workspace binding
   bool bound = false;
@@ -108,6 +114,12 @@ struct hmp_net {
   uint32_t rng_step = 0;
   bool step_dev = false;  // dropout step offset read from d_state->step
   GradReduceDyn dyn;
+
+  // parallel branches (side streams; under capture they become branches of the hipGraph)
+  bool use_branches = false;
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t evs[32];
+  int n_evs = 0, ev_i = 0;
 
   // profiling
   bool prof = false;
@@ -268,8 +280,14 @@ int build_tables(hmp_net* n) {
   std::vector<GradSeg> gs;
   std::vector<int64_t> ges;
   int64_t prow = 0, gel = 0;
-  auto push_pack = [&](const PackSeg& s) { ps.push_back(s); prs.push_back(prow); prow += s.rows_pad; };
-  auto push_grad = [&](GradSeg g) { gs.push_back(g); ges.push_back(gel); gel += (int64_t)g.rows * g.cols; };
+  auto push_pack = [&](const PackSeg& s) {
+    ps.push_back(s); prs.push_back(prow); prow += s.rows_pad;
+    if (s.rows_pad > n->max_pack_rows) n->max_pack_rows = s.rows_pad;
+  };
+  auto push_grad = [&](GradSeg g) {
+    gs.push_back(g); ges.push_back(gel); gel += (int64_t)g.rows * g.cols;
+    if ((int64_t)g.rows * g.cols > n->max_grad_elems) n->max_grad_elems = (int64_t)g.rows * g.cols;
+  };
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
     const LayerLayout& Y = n->lay[l];
@@ -428,6 +446,7 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
     P.d_t_col = (int32_t*)take((size_t)ce[e] * 4);
     P.d_t_pos = (int32_t*)take((size_t)ce[e] * 4);
     n->plan_scratch[e] = (int*)take(plan_scratch_ints(ce[e], ns, nd) * 4);
+    n->degf[e] = (float*)take((size_t)nd * 4);
   }
   n->d_packed = (float*)take((size_t)n->packed_floats * 4);
   n->d_slabs = (float*)take((size_t)n->slab_floats * 4);
@@ -466,6 +485,7 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
   n->cap_out = cap_out;
   n->d_out = (float*)take((size_t)cap_out * n->out_ld * 4);
   n->d_gout = (float*)take((size_t)cap_out * n->out_ld * 4);
+  n->d_row_lv = (float*)take((size_t)cap_out * 2 * 4);
   return off;
 }
 
@@ -564,6 +584,15 @@ struct Scope {
   }
 };
 
+// `to` waits for everything enqueued on `from` so far (fork when to is a side stream, join when to is the main stream)
+int fork_to(hmp_net* n, hipStream_t from, hipStream_t to) {
+  hipEvent_t e = n->evs[n->ev_i];
+  n->ev_i = (n->ev_i + 1) % n->n_evs;
+  HMP_HIP(hipEventRecord(e, from));
+  HMP_HIP(hipStreamWaitEvent(to, e, 0));
+  return HMP_OK;
+}
+
 enum { KC_PLAN = 0, KC_PACK, KC_GEMM_FWD, KC_AGG_FWD, KC_LOSS, KC_AGG_BWD, KC_GEMM_BWD, KC_GRAD_REDUCE, KC_ADAM, KC_GAT_FWD, KC_GAT_BWD, KC_POOL };
 
 DropCfg make_drop(const hmp_net* n, float p, uint32_t stream) {
@@ -618,8 +647,11 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
   PlanBatch pb;
   memset(&pb, 0, sizeof(pb));
   pb.n = n->ET;
+  pb.need_tpos = n->any_gat ? 1 : 0;
+  pb.clear_first = 0;  // counters were zeroed at bind time and every build leaves them zero
   for (int e = 0; e < n->ET; ++e) {
     PlanJob& J = pb.j[e];
+    J.degf = n->degf[e];
     hmp_plan& P = n->plan[e];
     P.n_src = b->n_nodes[n->spec.edge_src[e]];
     P.n_dst = b->n_nodes[n->spec.edge_dst[e]];
@@ -654,14 +686,20 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   HMP_TRY(check_batch(n, b));
   n->batch = *b;
   const hmp_net_spec& S = n->spec;
-  HMP_TRY(run_plan(n, b, st));
+  // The parameter pack and the layer-0 projection do not depend on the plan: they run on a side stream next to the
+  // (4-5 dependent launches of the) plan build and join before the first aggregation.  Under capture this becomes
+  // two parallel branches of the hipGraph.
+  hipStream_t main_st = st;
+  hipStream_t side = n->use_branches ? n->side[0] : main_st;
+  if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   {
-    Scope sc(n, KC_PACK, st);
-    HMP_TRY(pack_launch(n->d_pack_segs, n->n_pack, n->pack_rows, n->d_pack_row_start, d_params, n->d_packed, st));
+    Scope sc(n, KC_PACK, side);
+    HMP_TRY(pack_launch(n->d_pack_segs, n->n_pack, n->max_pack_rows, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
   }
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
+    st = (l == 0) ? side : main_st;
     {  // grouped projection
       Scope sc(n, KC_GEMM_FWD, st);
       std::vector<GemmProblem> ps;
@@ -678,6 +716,11 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         ps.push_back(p);
       }
       HMP_TRY(gemm_many(ps, false, st, nullptr));
+    }
+    if (l == 0) {
+      HMP_TRY(run_plan(n, b, main_st));
+      if (side != main_st) HMP_TRY(fork_to(n, side, main_st));  // join
+      st = main_st;
     }
     if (Y.kind == HMP_CONV_GAT) {
       Scope sc(n, KC_GAT_FWD, st);
@@ -781,13 +824,19 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           if (C.src != s) continue;
           TAggOut& O = T.out[T.n_out++];
           const hmp_plan& P = n->plan[C.edge_type];
-          O.t_rowptr = P.d_t_rowptr; O.t_col = P.d_t_col; O.rowptr = P.d_rowptr;
+          O.t_rowptr = P.d_t_rowptr; O.t_col = P.d_t_col; O.rowptr = P.d_rowptr; O.degf = n->degf[C.edge_type];
           int ldg;
           O.g = g_of(C.dst, ldg);
           O.ldg = ldg; O.coff = Y.conv[c].coff; O.F = fpad(C.f_out);
         }
       }
       HMP_TRY(agg_bwd_launch(a, st));
+    }
+    // dZ[l] is complete: the weight-gradient GEMM of this layer leaves the critical path (side stream / graph branch)
+    hipStream_t wst = st;
+    if (n->use_branches) {
+      wst = n->side[1];
+      HMP_TRY(fork_to(n, st, wst));
     }
     const bool need_dx = (l > 0) || (d_gx != nullptr);
     if (need_dx) {  // input gradient, masked by the previous layer's activation/dropout derivative
@@ -817,7 +866,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       HMP_TRY(gemm_many(ps, false, st, nullptr));
     }
     {  // weight + bias gradient: dWp = dZ^T * [H | 1], split over node chunks (+ GAT: bias column sums, d V_edge)
-      Scope sc(n, KC_GEMM_BWD, st);
+      Scope sc(n, KC_GEMM_BWD, wst);
       std::vector<GemmProblem> ps;
       std::vector<int> ids;
       auto add = [&](int sid, const GemmProblem& p) {
@@ -868,13 +917,17 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         }
       }
       std::vector<int> ks;
-      HMP_TRY(gemm_many(ps, true, st, &ks));
+      HMP_TRY(gemm_many(ps, true, wst, &ks));
       for (size_t i = 0; i < ids.size(); ++i) n->dyn.n_slabs[ids[i]] = (unsigned char)ks[i];
     }
   }
+  if (n->use_branches) HMP_TRY(fork_to(n, n->side[1], st));  // join the weight-gradient branch
   {
     Scope sc(n, KC_GRAD_REDUCE, st);
-    HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->n_grad, n->grad_elems, n->d_grad_elem_start, n->dyn, n->d_slabs, d_params, d_grads, st));
+    const int64_t na = n->spec.n_active_params;
+    HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->n_grad, n->max_grad_elems, n->dyn, n->d_slabs, d_params, d_grads,
+                               n->fin_loss ? n->d_row_lv : nullptr, b->n_out, d_grads + na, n->d_state, st));
+    n->fin_loss = false;
   }
   return HMP_OK;
 }
@@ -891,6 +944,16 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
   n->spec = *spec;
   int r = build_layout(n);
   if (r == HMP_OK) r = build_tables(n);
+  if (r == HMP_OK) {
+    const char* nb = getenv("HMP_NO_BRANCH");
+    bool ok = !(nb && nb[0] == '1');
+    for (int i = 0; i < 2 && ok; ++i) ok = hipStreamCreateWithFlags(&n->side[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 32 && ok; ++i) {
+      ok = hipEventCreateWithFlags(&n->evs[i], hipEventDisableTiming) == hipSuccess;
+      if (ok) n->n_evs = i + 1;
+    }
+    n->use_branches = ok && n->n_evs == 32;
+  }
   if (r != HMP_OK) {
     hmp_net_destroy(n);
     return r;
@@ -902,6 +965,9 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
 extern "C" void hmp_net_destroy(hmp_net* n) {
   if (!n) return;
   for (auto& r : n->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (int i = 0; i < n->n_evs; ++i) (void)hipEventDestroy(n->evs[i]);
+  for (int i = 0; i < 2; ++i)
+    if (n->side[i]) (void)hipStreamDestroy(n->side[i]);
   if (n->d_pack_segs) (void)hipFree(n->d_pack_segs);
   if (n->d_pack_row_start) (void)hipFree(n->d_pack_row_start);
   if (n->d_grad_segs) (void)hipFree(n->d_grad_segs);
@@ -959,8 +1025,10 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
   const int64_t na = n->spec.n_active_params;
   {
     Scope sc(n, KC_LOSS, st);
-    HMP_TRY(masked_ce_launch(out_ptr(n), n->out_ld, batch->n_out, n->out_dim, batch->d_labels, args->ignored_label, n->d_gout,
-                             n->out_ld, d_grads + na, n->d_state, st));
+    HMP_TRY(masked_ce_rows_launch(out_ptr(n), n->out_ld, batch->n_out, n->out_dim, batch->d_labels, args->ignored_label, n->d_gout,
+                                  n->out_ld, n->d_row_lv, n->d_state, st));
+    n->fin_loss = true;  // {loss_sum, count} -> d_grads[na], d_grads[na + 1] in the gradient un-pack
+    (void)na;
   }
   return backward_impl(n, n->d_gout, n->out_ld, d_grads, d_params, nullptr, st);
 }
@@ -972,9 +1040,9 @@ extern "C" int hmp_net_step_adam(hmp_net* n, float* d_params, const float* d_gra
   hipStream_t st = (hipStream_t)stream;
   const int64_t na = n->spec.n_active_params;
   Scope sc(n, KC_ADAM, st);
-  HMP_TRY(adam_launch(d_params, d_grads, d_m, d_v, na, args->lr, args->beta1, args->beta2, args->eps, args->weight_decay, 0,
-                      &n->d_state->step, d_grads + na + 1, st));
-  return step_increment_launch(n->d_state, st);
+  // t = the step counter the pack kernel bumped at the head of this step
+  return adam_launch(d_params, d_grads, d_m, d_v, na, args->lr, args->beta1, args->beta2, args->eps, args->weight_decay, 0,
+                     &n->d_state->step, d_grads + na + 1, st);
 }
 
 extern "C" int hmp_net_read_state(hmp_net* n, int32_t* step, int32_t* status, void* stream) {

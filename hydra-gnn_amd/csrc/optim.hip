@@ -4,9 +4,34 @@
 namespace hmp {
 
 // ---------------------------------------------------------------------------------------------
-// masked cross entropy (models/utils.py:143-148 with mask = label != ignored): one block, one
-// wavefront per row, fixed-order reductions => deterministic.  grad is the gradient of the SUM loss.
+// masked cross entropy (models/utils.py:143-148 with mask = label != ignored).  grad is the gradient of the SUM
+// loss.  Unit entry point: one block, one wavefront per row, fixed-order reductions => deterministic.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ce_row(const float* __restrict__ lr, int n_classes, int64_t y, int64_t ignored, int lane,
+                                       float* __restrict__ grow, int ldg, float& loss, float& valid, int& bad) {
+  const bool is_valid = (y != ignored);
+  if (is_valid && (y < 0 || y >= n_classes)) bad = 1;
+  float m = -INFINITY;
+  for (int c = lane; c < n_classes; c += 64) m = fmaxf(m, lr[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int c = lane; c < n_classes; c += 64) s += expf(lr[c] - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float lse = m + logf(s);
+  const bool use = is_valid && y >= 0 && y < n_classes;
+  if (grow) {
+    for (int c = lane; c < ldg; c += 64) {
+      float g = 0.f;
+      if (use && c < n_classes) g = expf(lr[c] - lse) - (c == (int)y ? 1.f : 0.f);
+      grow[c] = g;
+    }
+  }
+  loss = use ? (lse - lr[y]) : 0.f;
+  valid = use ? 1.f : 0.f;
+}
+
 __global__ __launch_bounds__(1024) void masked_ce_kernel(const float* __restrict__ logits, int ldl, int n_rows, int n_classes,
                                                          const int64_t* __restrict__ labels, int64_t ignored, float* __restrict__ grad,
                                                          int ldg, float* __restrict__ out2, NetState* state) {
@@ -16,31 +41,10 @@ __global__ __launch_bounds__(1024) void masked_ce_kernel(const float* __restrict
   float loss = 0.f, cnt = 0.f;
   int bad = 0;
   for (int row = w; row < n_rows; row += 16) {
-    const float* lr = logits + (int64_t)row * ldl;
-    const int64_t y = labels[row];
-    const bool valid = (y != ignored);
-    if (valid && (y < 0 || y >= n_classes)) bad = 1;
-    float m = -INFINITY;
-    for (int c = lane; c < n_classes; c += 64) m = fmaxf(m, lr[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    float s = 0.f;
-    for (int c = lane; c < n_classes; c += 64) s += expf(lr[c] - m);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float lse = m + logf(s);
-    const bool use = valid && y >= 0 && y < n_classes;
-    if (grad) {
-      for (int c = lane; c < ldg; c += 64) {
-        float g = 0.f;
-        if (use && c < n_classes) g = expf(lr[c] - lse) - (c == (int)y ? 1.f : 0.f);
-        grad[(int64_t)row * ldg + c] = g;
-      }
-    }
-    if (use && lane == 0) {
-      loss += lse - lr[y];
-      cnt += 1.f;
-    }
+    float l, v;
+    ce_row(logits + (int64_t)row * ldl, n_classes, labels[row], ignored, lane, grad ? grad + (int64_t)row * ldg : nullptr, ldg, l, v, bad);
+    loss += l;
+    cnt += v;
   }
   if (lane == 0) { s_loss[w] = loss; s_cnt[w] = cnt; }
   if (bad && state) atomicOr(&state->status, 2);
@@ -61,13 +65,40 @@ int masked_ce_launch(const float* logits, int ldl, int n_rows, int n_classes, co
   return HMP_OK;
 }
 
+// executor version: one wavefront per row over many blocks; per-row {loss, valid} go to row_lv[2*row ..] and are summed in
+// fixed order by block (0,0) of the gradient un-pack kernel, which runs later in the same step anyway
+__global__ __launch_bounds__(256) void masked_ce_rows_kernel(const float* __restrict__ logits, int ldl, int n_rows, int n_classes,
+                                                             const int64_t* __restrict__ labels, int64_t ignored, float* __restrict__ grad,
+                                                             int ldg, float* __restrict__ row_lv, NetState* state) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float l, v;
+  int bad = 0;
+  ce_row(logits + (int64_t)row * ldl, n_classes, labels[row], ignored, lane, grad + (int64_t)row * ldg, ldg, l, v, bad);
+  if (lane == 0) {
+    row_lv[2 * row] = l;
+    row_lv[2 * row + 1] = v;
+    if (bad) atomicOr(&state->status, 2);
+  }
+}
+
+int masked_ce_rows_launch(const float* logits, int ldl, int n_rows, int n_classes, const int64_t* labels, int64_t ignored, float* grad,
+                          int ldg, float* row_lv, NetState* state, hipStream_t st) {
+  if (n_rows == 0) return HMP_OK;
+  hipLaunchKernelGGL(masked_ce_rows_kernel, dim3(cdiv(n_rows, 4)), dim3(256), 0, st, logits, ldl, n_rows, n_classes, labels, ignored,
+                     grad, ldg, row_lv, state);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adam with coupled L2 (torch.optim.Adam semantics, base_training_job.py:181-185)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                                                    int step_host, const int* __restrict__ step_dev, const float* __restrict__ d_count) {
-  const int t = step_dev ? (*step_dev + 1) : step_host;
+  const int t = step_dev ? *step_dev : step_host;
   const float bc1 = 1.f - powf(b1, (float)t);
   const float bc2 = 1.f - powf(b2, (float)t);
   const float step_size = lr / bc1;
@@ -99,13 +130,6 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float l
   return HMP_OK;
 }
 
-__global__ void step_increment_kernel(NetState* s) { s->step += 1; }
-int step_increment_launch(NetState* state, hipStream_t st) {
-  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, st, state);
-  HMP_LAUNCH_CHECK();
-  return HMP_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // dropout keep-mask export (tests replay the engine's masks in the oracle)
 // ---------------------------------------------------------------------------------------------
@@ -123,68 +147,58 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(DropCfg cfg, int n_ro
 }
 
 // ---------------------------------------------------------------------------------------------
-// pack: flat parameters -> per-(layer, source type) stacked weight operand.  One thread block row per
-// packed row; a packed row is the SUM of up to AGG_MAX_IN parameter rows (root weights of every conv
-// reaching the node type add up: sum_e W_r,e * x == (sum_e W_r,e) * x) or zero padding.
+// pack: flat parameters -> per-(layer, source type) stacked weight operand.  grid = (row chunks, segments): a block
+// reads its segment descriptor once and writes 4 packed rows (64 lanes per row).  Block (0,0) also starts the step:
+// it bumps the device step counter that dropout and Adam read later in the same step.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ segs, int n_segs, const int64_t* __restrict__ row_start,
-                                                   const float* __restrict__ params, float* __restrict__ packed) {
-  const int64_t total_rows = row_start[n_segs];
-  for (int64_t gr = blockIdx.x; gr < total_rows; gr += gridDim.x) {
-    int lo = 0, hi = n_segs - 1;  // last seg with row_start <= gr
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (row_start[mid] <= gr) lo = mid; else hi = mid - 1;
+__global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ segs, const float* __restrict__ params,
+                                                   float* __restrict__ packed, NetState* step_state) {
+  if (step_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_state->step += 1;
+  const PackSeg S = segs[blockIdx.y];
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= S.rows_pad) return;
+  float* dst = packed + S.dst + (int64_t)r * S.ld_dst;
+  for (int c = threadIdx.x & 63; c < S.ld_dst; c += 64) {
+    float v = 0.f;
+    if (S.kind == PACK_SUM) {
+      if (r < S.rows && c < S.cols)
+        for (int q = 0; q < S.nsrc; ++q) v += params[S.src[q] + (int64_t)r * S.ld_src + c];
+    } else if (S.kind == PACK_HEADS) {
+      const int h = r / S.Cp, cc = r % S.Cp;
+      if (h < S.H && cc < S.C && c < S.cols) v = params[S.src[0] + (int64_t)(h * S.C + cc) * S.ld_src + c];
+    } else if (S.kind == PACK_ATTDOT) {  // row r = head
+      if (r < S.H && c < S.cols)
+        for (int cc = 0; cc < S.C; ++cc)
+          v += params[S.att + r * S.C + cc] * params[S.src[0] + (int64_t)(r * S.C + cc) * S.ld_src + c];
+    } else {  // PACK_ATTDOT_T: row r = edge-attribute dimension d, column c = head
+      if (r < S.rows && c < S.H)
+        for (int cc = 0; cc < S.C; ++cc)
+          v += params[S.att + c * S.C + cc] * params[S.src[0] + (int64_t)(c * S.C + cc) * S.ld_src + r];
     }
-    const PackSeg S = segs[lo];
-    const int r = (int)(gr - row_start[lo]);
-    float* dst = packed + S.dst + (int64_t)r * S.ld_dst;
-    for (int c = threadIdx.x; c < S.ld_dst; c += blockDim.x) {
-      float v = 0.f;
-      if (S.kind == PACK_SUM) {
-        if (r < S.rows && c < S.cols)
-          for (int q = 0; q < S.nsrc; ++q) v += params[S.src[q] + (int64_t)r * S.ld_src + c];
-      } else if (S.kind == PACK_HEADS) {
-        const int h = r / S.Cp, cc = r % S.Cp;
-        if (h < S.H && cc < S.C && c < S.cols) v = params[S.src[0] + (int64_t)(h * S.C + cc) * S.ld_src + c];
-      } else if (S.kind == PACK_ATTDOT) {  // row r = head
-        if (r < S.H && c < S.cols)
-          for (int cc = 0; cc < S.C; ++cc)
-            v += params[S.att + r * S.C + cc] * params[S.src[0] + (int64_t)(r * S.C + cc) * S.ld_src + c];
-      } else {  // PACK_ATTDOT_T: row r = edge-attribute dimension d, column c = head
-        if (r < S.rows && c < S.H)
-          for (int cc = 0; cc < S.C; ++cc)
-            v += params[S.att + c * S.C + cc] * params[S.src[0] + (int64_t)(c * S.C + cc) * S.ld_src + r];
-      }
-      dst[c] = v;
-    }
+    dst[c] = v;
   }
 }
 
-int pack_launch(const PackSeg* d_segs, int n_segs, int64_t total_rows, const int64_t* d_row_start, const float* d_params,
-                float* d_packed, hipStream_t st) {
-  if (n_segs == 0 || total_rows == 0) return HMP_OK;
-  const int grid = (int)(total_rows > 4096 ? 4096 : total_rows);
-  hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, d_segs, n_segs, d_row_start, d_params, d_packed);
+int pack_launch(const PackSeg* d_segs, int n_segs, int max_rows_pad, const float* d_params, float* d_packed, NetState* step_state,
+                hipStream_t st) {
+  if (n_segs == 0 || max_rows_pad == 0) return HMP_OK;
+  hipLaunchKernelGGL(pack_kernel, dim3(cdiv(max_rows_pad, 4), n_segs), dim3(256), 0, st, d_segs, d_params, d_packed, step_state);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // grad reduce: split-K slabs of the packed weight gradients -> flat gradient buffer (fixed slab order).
+// grid = (element chunks of 1024, segments).  Block (0,0) additionally sums the per-row {loss, valid} pairs of the
+// loss kernel in fixed order into out2 = {loss_sum, count} (the tail of the flat gradient buffer).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, int n_segs, const int64_t* __restrict__ elem_start,
-                                                          const GradReduceDyn dyn, const float* __restrict__ slabs,
-                                                          const float* __restrict__ params, float* __restrict__ grads) {
-  const int64_t total = elem_start[n_segs];
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    int lo = 0, hi = n_segs - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (elem_start[mid] <= g) lo = mid; else hi = mid - 1;
-    }
-    const GradSeg& S = segs[lo];
-    const int64_t i = g - elem_start[lo];
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, const GradReduceDyn dyn,
+                                                          const float* __restrict__ slabs, const float* __restrict__ params,
+                                                          float* __restrict__ grads, const float* __restrict__ row_lv, int n_lv_rows,
+                                                          float* __restrict__ out2, NetState* state) {
+  const GradSeg& S = segs[blockIdx.y];
+  const int64_t n_el = (int64_t)S.rows * S.cols;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n_el && i < (int64_t)(blockIdx.x + 1) * 1024; i += 256) {
     const int r = (int)(i / S.cols), c = (int)(i % S.cols);
     float total = 0.f;
     for (int ti = 0; ti < S.n_terms; ++ti) {
@@ -226,14 +240,32 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
     }
     grads[S.dst + i] = total;
   }
+  if (row_lv != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+    __shared__ float sl[256], sv[256];
+    float l = 0.f, v = 0.f;
+    for (int r = threadIdx.x; r < n_lv_rows; r += 256) { l += row_lv[2 * r]; v += row_lv[2 * r + 1]; }
+    sl[threadIdx.x] = l;
+    sv[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sv[threadIdx.x] += sv[threadIdx.x + o]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out2[0] = sl[0];
+      out2[1] = sv[0];
+      if (state) { state->loss_sum = sl[0]; state->count = sv[0]; }
+    }
+  }
 }
 
-int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t total_elems, const int64_t* d_elem_start, const GradReduceDyn& dyn,
-                       const float* d_slabs, const float* d_params, float* d_grads, hipStream_t st) {
-  if (n_segs == 0 || total_elems == 0) return HMP_OK;
-  const int64_t want = cdiv(total_elems, 256);
-  const int grid = (int)(want > 2048 ? 2048 : want);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, st, d_segs, n_segs, d_elem_start, dyn, d_slabs, d_params, d_grads);
+int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t max_elems, const GradReduceDyn& dyn, const float* d_slabs,
+                       const float* d_params, float* d_grads, const float* row_lv, int n_lv_rows, float* out2, NetState* state,
+                       hipStream_t st) {
+  if (n_segs == 0) return HMP_OK;
+  const int gx = (int)(max_elems > 0 ? cdiv(max_elems, 1024) : 1);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(gx, n_segs), dim3(256), 0, st, d_segs, dyn, d_slabs, d_params, d_grads, row_lv,
+                     n_lv_rows, out2, state);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

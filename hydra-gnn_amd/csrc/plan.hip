@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
     const int* ptr = dir ? J.t_rowptr : J.rowptr;
     const int* tmp = dir ? J.tmp_out : J.tmp_in;
     const int b = ptr[row], deg = ptr[row + 1] - b;
+    if (lane == 0) {
+      // this wave is the last reader of the row's counters: leave them zero for the next build
+      if (dir) { J.cnt_out[row] = 0; J.cur_out[row] = 0; }
+      else { J.cnt_in[row] = 0; J.cur_in[row] = 0; if (J.degf) J.degf[row] = (float)(deg > 1 ? deg : 1); }
+    }
     for (int c = lane; c < deg; c += 64) {
       const int mine = tmp[b + c];
       int rank = 0;
@@ -153,9 +158,9 @@ int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
     pb.edge_start[j + 1] = pb.edge_start[j] + J.E;
     pb.row_start[2 * j + 1] = pb.row_start[2 * j] + J.n_dst;
     pb.row_start[2 * j + 2] = pb.row_start[2 * j + 1] + J.n_src;
-    // counters + cursors of one job are one contiguous block (see plan_carve)
+    // counters + cursors of one job are one contiguous block (see plan_carve); the rank kernel re-zeroes them
     const size_t zero_ints = (size_t)(J.tmp_in - J.cnt_in);
-    if (zero_ints > 0) HMP_HIP(hipMemsetAsync(J.cnt_in, 0, zero_ints * sizeof(int), st));
+    if (pb.clear_first && zero_ints > 0) HMP_HIP(hipMemsetAsync(J.cnt_in, 0, zero_ints * sizeof(int), st));
   }
   const int64_t E = pb.edge_start[pb.n];
   const int64_t rows = pb.row_start[2 * pb.n];
@@ -173,8 +178,10 @@ int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
     const int rg = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
     hipLaunchKernelGGL(plan_rank_kernel, dim3(rg), dim3(256), 0, st, pb);
     HMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(plan_link_kernel, dim3(eg), dim3(256), 0, st, pb);
-    HMP_LAUNCH_CHECK();
+    if (pb.need_tpos) {
+      hipLaunchKernelGGL(plan_link_kernel, dim3(eg), dim3(256), 0, st, pb);
+      HMP_LAUNCH_CHECK();
+    }
   }
   return HMP_OK;
 }
@@ -193,6 +200,8 @@ extern "C" int hmp_plan_build(const int64_t* d_edge_index, hmp_plan plan, void* 
   PlanBatch pb;
   memset(&pb, 0, sizeof(pb));
   pb.n = 1;
+  pb.need_tpos = 1;
+  pb.clear_first = 1;
   PlanJob& J = pb.j[0];
   J.ei = d_edge_index;
   J.E = plan.n_edges;
