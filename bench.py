@@ -183,7 +183,8 @@ def main():
             "nodes_per_rank": dict(zip(net.native().node_types, step._holder.n_nodes if step._holder else [])),
             "edges_per_rank": int(sum(step._holder.n_edges)) if step._holder else None,
             "parallelism": f"dp{world}",
-            "launch": "eager" if args.no_graph else "hipGraph replay (2 graphs/step around the all-reduce)",
+            "launch": "eager" if args.no_graph else ("hipGraph replay, 1 graph/step" if world == 1 else
+                                                      "hipGraph replay, 2 graphs/step around the all-reduce"),
             "final_loss": round(final_loss, 5),
         },
     }

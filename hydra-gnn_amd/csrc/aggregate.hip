@@ -193,9 +193,18 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
       if (D.bias) { Acc<VEC> b; b.load(D.bias + c); tot[q].add(b); }
     }
   }
-  for (int ii = 0; ii < D.n_in; ++ii) {
+  // all row extents first: one round trip for every incoming edge type instead of one per type
+  int rb[AGG_MAX_IN], re[AGG_MAX_IN];
+#pragma unroll
+  for (int ii = 0; ii < AGG_MAX_IN; ++ii) {
+    rb[ii] = re[ii] = 0;
+    if (ii < D.n_in) { rb[ii] = D.in[ii].rowptr[row]; re[ii] = D.in[ii].rowptr[row + 1]; }
+  }
+#pragma unroll
+  for (int ii = 0; ii < AGG_MAX_IN; ++ii) {
+    if (ii >= D.n_in) break;
     const AggIn& I = D.in[ii];
-    const int b = I.rowptr[row], e = I.rowptr[row + 1];
+    const int b = rb[ii], e = re[ii];
     if (e == b) continue;
     Acc<VEC> acc[NV];
 #pragma unroll
@@ -216,7 +225,9 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
       float v = tot[q].at(i);
       if (D.act == HMP_ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (D.act == HMP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
-      if (D.drop_on) v = keep[i] ? v * D.drop.scale : 0.f;
+      // a dropped element is stored as -0.0f (a kept one that happens to be zero as +0.0f): numerically both are 0 for
+      // every consumer, and the backward pass reads the keep bit off the sign instead of regenerating Philox draws
+      if (D.drop_on) v = keep[i] ? (v * D.drop.scale + 0.0f) : -0.0f;  // "+ 0.0f": a kept -0.0 becomes +0.0
       tot[q].at(i) = v;
     }
     tot[q].store(D.out + (int64_t)row * D.ldo + c);
@@ -234,12 +245,20 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   const int row = (blockIdx.x - S.block_start) * rpb + threadIdx.x / GS;
   if (row >= S.n_rows) return;
   const int c0 = (threadIdx.x % GS) * VEC;
-  for (int oi = 0; oi < S.n_out; ++oi) {
+  int rb[AGG_MAX_IN], re[AGG_MAX_IN];
+#pragma unroll
+  for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
+    rb[oi] = re[oi] = 0;
+    if (oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
+  }
+#pragma unroll
+  for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
+    if (oi >= S.n_out) break;
     const TAggOut& O = S.out[oi];
     Acc<VEC> acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q].zero();
-    gather_sum_w<GS, NV, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, O.t_rowptr[row], O.t_rowptr[row + 1], c0, O.F);
+    gather_sum_w<GS, NV, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, rb[oi], re[oi], c0, O.F);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c = c0 + q * GS * VEC;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
     if (fdrop) {
       bool k4[4];
       drop_keep4(fcfg, (uint32_t)row * (uint32_t)(D.ldo >> 2) + (uint32_t)(col >> 2), k4);
-      v = k4[col & 3] ? v * fcfg.scale : 0.f;
+      v = k4[col & 3] ? (v * fcfg.scale + 0.0f) : -0.0f;  // dropped: -0.0f (sign bit = "dropped", see gemm.hip epilogue)
     }
     return v;
   };

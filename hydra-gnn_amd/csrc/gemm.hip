@@ -32,10 +32,67 @@ struct TileRegs {
   float4 v[NV];
 };
 
+// Fast path: NO control flow between the loads (a branchy loader makes hipcc drain vmcnt between slots, i.e. one load in
+// flight at a time).  Out-of-range rows / k are CLAMPED to an in-range address and zeroed by selects afterwards, so any
+// K stage of a k-contiguous operand (also the tail stage) and any K stage of an r-contiguous operand whose tile width is
+// fully in range take this path.  A 16/8-byte vector never leaves the row: ld is a multiple of the vector width and the
+// vector starts below kend <= ld.
+template <int ROWS, int BK, int VEC>
+__device__ __forceinline__ void tile_load_fast(TileRegs<ROWS, BK>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
+                                               int R, int k0, int kend) {
+  constexpr int NV = TileRegs<ROWS, BK>::NV;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * 256;
+    const float* src;
+    bool m0, m1, m2, m3;
+    if (kcontig) {
+      const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
+      const int gr = r0 + r, gk = k0 + k4;
+      const bool rlive = gr < R;
+      m0 = rlive && gk + 0 < kend; m1 = rlive && gk + 1 < kend; m2 = rlive && gk + 2 < kend; m3 = rlive && gk + 3 < kend;
+      // clamp: row to the last row; k to the start of the stage (always < kend) when the slot starts out of range
+      const int gkc = (gk < kend) ? gk : k0;
+      src = p + (int64_t)(rlive ? gr : R - 1) * ld + gkc;
+      if (VEC == 1) {  // scalar rows may end right at kend: clamp every element
+        float e0 = src[0];
+        float e1 = src[(gk + 1 < kend) ? 1 : 0], e2 = src[(gk + 2 < kend) ? 2 : 0], e3 = src[(gk + 3 < kend) ? 3 : 0];
+        t.v[i] = make_float4(m0 ? e0 : 0.f, m1 ? e1 : 0.f, m2 ? e2 : 0.f, m3 ? e3 : 0.f);
+        continue;
+      }
+      if (VEC == 2) {  // the second pair may start at/after kend (possibly the end of the buffer): re-read the first pair then
+        const float2 a = *reinterpret_cast<const float2*>(src);
+        const float2 b = *reinterpret_cast<const float2*>(src + ((gk + 2 < kend) ? 2 : 0));
+        t.v[i] = make_float4(m0 ? a.x : 0.f, m1 ? a.y : 0.f, m2 ? b.x : 0.f, m3 ? b.y : 0.f);
+        continue;
+      }
+    } else {
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      const int gk = k0 + k;
+      const bool klive = gk < kend;
+      m0 = m1 = m2 = m3 = klive;
+      src = p + (int64_t)(klive ? gk : k0) * ld + (r0 + r4);
+    }
+    float4 val;
+    if (VEC == 4) {
+      val = *reinterpret_cast<const float4*>(src);
+    } else if (VEC == 2) {
+      const float2 a = *reinterpret_cast<const float2*>(src);
+      const float2 b = *reinterpret_cast<const float2*>(src + 2);
+      val = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+      val = make_float4(src[0], src[1], src[2], src[3]);
+    }
+    t.v[i] = make_float4(m0 ? val.x : 0.f, m1 ? val.y : 0.f, m2 ? val.z : 0.f, m3 ? val.w : 0.f);
+  }
+}
+
+// Edge path (last K stage, last column tile, ones column): bounds-checked element by element.
 // vec: 4 = 16-byte loads, 2 = 8-byte loads (rows only 8-byte aligned, e.g. ld = 306), 1 = scalar
 template <int ROWS, int BK>
-__device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
-                                          int R, int n_real, int aug, int k0, int kend, int vec) {
+__device__ __forceinline__ void tile_load_edge(TileRegs<ROWS, BK>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
+                                               int R, int n_real, int aug, int k0, int kend, int vec) {
   constexpr int NV = TileRegs<ROWS, BK>::NV;
   const int tid = threadIdx.x;
 #pragma unroll
@@ -86,7 +143,24 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& t, const float* __
   }
 }
 
-// LDS image is [k][LD] with LD = ROWS + 4
+template <int ROWS, int BK>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
+                                          int R, int n_real, int aug, int k0, int kend, int vec) {
+  // all conditions are block-uniform
+  const bool fast = kcontig || (r0 + ROWS <= n_real);
+  if (fast) {
+    if (vec == 4) tile_load_fast<ROWS, BK, 4>(t, p, ld, kcontig, r0, R, k0, kend);
+    else if (vec == 2) tile_load_fast<ROWS, BK, 2>(t, p, ld, kcontig, r0, R, k0, kend);
+    else tile_load_fast<ROWS, BK, 1>(t, p, ld, kcontig, r0, R, k0, kend);
+  } else {
+    tile_load_edge<ROWS, BK>(t, p, ld, kcontig, r0, R, n_real, aug, k0, kend, vec);
+  }
+}
+
+// LDS image is [k][LD] with LD = ROWS + 4.  A k-contiguous operand is transposed on the way in (each lane holds 4
+// consecutive k of one row): written plainly, 32 lanes (k = 0,4,8,..) would hit 2 banks (4*LD = 16 mod 32: 16-way
+// conflict), so row r of k-row k is ROTATED to column (r + k/4) mod ROWS: the 32 lanes then land on 32 different banks
+// (bank = 17*(k/4) + r + const), and the MFMA operand fetch (32 consecutive r of one k) stays conflict-free.
 template <int ROWS, int BK>
 __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& t, float* __restrict__ s, int kcontig) {
   constexpr int NV = TileRegs<ROWS, BK>::NV;
@@ -97,10 +171,11 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& t, float* _
     const int q = tid + i * 256;
     if (kcontig) {
       const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
-      s[(k4 + 0) * LD + r] = t.v[i].x;
-      s[(k4 + 1) * LD + r] = t.v[i].y;
-      s[(k4 + 2) * LD + r] = t.v[i].z;
-      s[(k4 + 3) * LD + r] = t.v[i].w;
+      const int rr = (r + (k4 >> 2)) & (ROWS - 1);
+      s[(k4 + 0) * LD + rr] = t.v[i].x;
+      s[(k4 + 1) * LD + rr] = t.v[i].y;
+      s[(k4 + 2) * LD + rr] = t.v[i].z;
+      s[(k4 + 3) * LD + rr] = t.v[i].w;
     } else {
       const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
       *reinterpret_cast<float4*>(&s[k * LD + r4]) = t.v[i];
@@ -125,7 +200,9 @@ __device__ __forceinline__ int vec_mode(const float* p, int ld, bool k_ok) {
 }
 
 template <int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
+// second launch-bound = waves per SIMD = blocks per CU for 256-thread blocks: >= 3 so that the ~600 workgroups of an MP3D
+// layer-0 projection are all resident at once (one round instead of two)
+__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
   constexpr int BM = 32 * WM, BN = 32 * WN, KW = 4 / (WM * WN);
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int STAGE = BK * LDA + BK * LDB;
@@ -140,8 +217,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   const GemmProblem& P = gb.p[pi];
   const int local = blockIdx.x - P.tile_start;
   const int tiles_mn = P.tiles_m * P.tiles_n;
-  const int z = local / tiles_mn, t = local % tiles_mn;
-  const int m0 = (t % P.tiles_m) * BM, n0 = (t / P.tiles_m) * BN;
+  // XCD-aware order (blocks b and b+8 share an XCD and its 4 MB L2; speed only, never correctness):
+  //  * split-K: the K chunk index is the fastest-varying part of the block id, so with ksplit = 8 (or 16) all tiles
+  //    of one chunk run on one XCD and its A/B panels are fetched into that L2 once;
+  //  * otherwise row tiles are grouped by 8 and the column tiles of one row tile are 8 block ids apart, so the row
+  //    panel of A (the big operand: nodes x features) is fetched once per XCD instead of once per column tile.
+  const int z = local % P.ksplit, t = local / P.ksplit;
+  (void)tiles_mn;
+  const int grp = t / (8 * P.tiles_n), within = t % (8 * P.tiles_n);
+  const int rows_in_grp = min(8, P.tiles_m - grp * 8);
+  const int m0 = (grp * 8 + within % rows_in_grp) * BM, n0 = (within / rows_in_grp) * BN;
   const int kbeg = z * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
 
@@ -174,14 +259,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     }
     constexpr int KS = BK / KW;
     const int klen = min(BK, kend - kt);  // tail stage: skip the k rows that are all zero
-    const float* ap = As + (kw * KS + (lane >> 5)) * LDA + wm * 32 + (lane & 31);
-    const float* bp = Bs + (kw * KS + (lane >> 5)) * LDB + wn * 32 + (lane & 31);
+    const int ma = wm * 32 + (lane & 31), mb = wn * 32 + (lane & 31);
+    // KS is a multiple of 4 and kk is even, so (k >> 2) does not depend on the lane half: the rotation is uniform
+    auto mfma_pair = [&](int kk) {
+      const int k = kw * KS + kk + (lane >> 5);
+      const int rot = (kw * KS + kk) >> 2;
+      const int ca = a_kcontig ? ((ma + rot) & (BM - 1)) : ma;  // undo the store rotation
+      const int cb = b_kcontig ? ((mb + rot) & (BN - 1)) : mb;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * LDA + ca], Bs[k * LDB + cb], acc, 0, 0, 0);
+    };
+    if (klen == BK) {
+      // full stage: straight-line code, so the scheduler can run the LDS operand reads ahead of the MFMAs
 #pragma unroll
-    for (int kk = 0; kk < KS; kk += 2) {
-      if (kw * KS + kk < klen) {
-        const float a = ap[kk * LDA];
-        const float b = bp[kk * LDB];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int kk = 0; kk < KS; kk += 2) mfma_pair(kk);
+    } else {
+      // tail stage: skip groups of 8 k rows that lie entirely in the zero padding
+#pragma unroll
+      for (int g = 0; g < KS; g += 8) {
+        if (kw * KS + g < klen) {
+#pragma unroll
+          for (int kk = g; kk < g + 8; kk += 2) mfma_pair(kk);
+        }
       }
     }
     __syncthreads();
@@ -208,8 +306,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   float* C = P.C + (int64_t)z * P.slab_stride;
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= P.N) return;
-  DropCfg dcfg;
-  if (P.epi == EPI_ACTMASK && P.drop_on) dcfg = drop_resolve(P.drop);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -217,15 +313,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     float v = acc[r];
     if (P.epi == EPI_ACTMASK) {
       const float h = P.H[(int64_t)row * P.ldh + col];
-      bool keep = true;
-      float scale = 1.f;
-      if (P.drop_on) {
-        bool k4[4];
-        drop_keep4(dcfg, (uint32_t)row * (uint32_t)(P.ldh >> 2) + (uint32_t)(col >> 2), k4);
-        keep = k4[col & 3];
-        scale = dcfg.scale;
-      }
-      v *= act_mask_factor(h, P.act, keep, scale);
+      // the forward stored dropped elements as -0.0f: the keep bit is the sign of a zero, no RNG replay needed
+      const bool keep = !P.drop_on || (__float_as_uint(h) != 0x80000000u);
+      v *= act_mask_factor(h, P.act, keep, P.drop_on ? P.drop.scale : 1.f);
     }
     C[(int64_t)row * P.ldc + col] = v;
   }
@@ -248,6 +338,7 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
       if (ks > max_by_k) ks = max_by_k;
       if (ks > max_slabs) ks = max_slabs;
       if (ks < 1) ks = 1;
+      while (ks & (ks - 1)) ks &= ks - 1;  // power of two (XCD affinity of the K chunks, see the kernel)
     }
     int kchunk = cdiv(cdiv(p.K, ks), BK) * BK;
     if (kchunk < BK) kchunk = BK;
@@ -267,13 +358,16 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm: %d problems", gb.n);
   int64_t tiles64 = 0;
+  int max_k = 0;
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative size");
     tiles64 += (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
+    max_k = p.K > max_k ? p.K : max_k;
   }
   // big problems: 64x64 tiles; small ones: 32x32 tiles with in-block K split and deep K stages
   if (tiles64 >= 1024) return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
+  if (max_k <= 64) return launch_cfg<1, 1, 64>(gb, want_split, max_slabs, st);
   return launch_cfg<1, 1, 128>(gb, want_split, max_slabs, st);
 }
 

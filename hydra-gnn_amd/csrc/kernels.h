@@ -141,9 +141,15 @@ struct PackSeg {
   int64_t src[AGG_MAX_IN];  // float offsets into the flat parameter buffer (summed)
 };
 struct NetState;
-// step_state != null: block (0,0) increments step_state->step (the fused step starts with the pack)
-int pack_launch(const PackSeg* d_segs, int n_segs, int max_rows_pad, const float* d_params, float* d_packed, NetState* step_state,
-                hipStream_t st);
+// block -> segment map of the table-driven kernels: segment i owns blocks [start[i], start[i+1]); passed by value so the
+// lookup is a scan of scalar (kernarg) loads instead of a dependent chain of global loads
+constexpr int SEG_MAX = 400;
+struct SegBlocks {
+  int n;
+  int start[SEG_MAX + 1];
+};
+// step_state != null: block 0 increments step_state->step (the fused step starts with the pack)
+int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, NetState* step_state, hipStream_t st);
 
 // A parameter gradient element (r, c) is the sum of up to 3 terms read from split-K slabs S (summed over slabs):
 //  GT_COPY       S[(r/C*Cp + r%C) * ld + c]                         (rows of the stacked operand; C = Cp: identity)
@@ -251,7 +257,7 @@ int gat_bwd1_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn,
 int gat_bwd2_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
 
 // row_lv != null: block (0,0) also sums the per-row {loss, valid} pairs (masked_ce_rows_launch) into out2 / state
-int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t max_elems, const GradReduceDyn& dyn, const float* d_slabs,
+int grad_reduce_launch(const GradSeg* d_segs, const SegBlocks& sb, const GradReduceDyn& dyn, const float* d_slabs,
                        const float* d_params, float* d_grads, const float* row_lv, int n_lv_rows, float* out2, NetState* state,
                        hipStream_t st);
 

@@ -85,6 +85,7 @@ struct hmp_net {
   int64_t grad_elems = 0;
   int max_pack_rows = 0;
   int64_t max_grad_elems = 0;
+  SegBlocks pack_sb, grad_sb;
   float* degf[HMP_MAX_EDGE_TYPES];  // max(in-degree,1) per destination node, by-product of the plan
   float* d_row_lv = nullptr;        // per output row {loss, valid} of the fused step's loss kernel
   bool fin_loss = false;            // the next gradient un-pack also finalises {loss_sum, count}
@@ -413,6 +414,14 @@ int build_tables(hmp_net* n) {
   ges.push_back(gel);
   n->n_pack = (int)ps.size(); n->pack_rows = prow;
   n->n_grad = (int)gs.size(); n->grad_elems = gel;
+  HMP_CHECK_ARG(ps.size() <= (size_t)SEG_MAX && gs.size() <= (size_t)SEG_MAX, "net: too many parameter segments (%zu / %zu > %d)",
+                ps.size(), gs.size(), SEG_MAX);
+  n->pack_sb.n = (int)ps.size();
+  n->pack_sb.start[0] = 0;
+  for (size_t i = 0; i < ps.size(); ++i) n->pack_sb.start[i + 1] = n->pack_sb.start[i] + cdiv(ps[i].rows_pad, 4);
+  n->grad_sb.n = (int)gs.size();
+  n->grad_sb.start[0] = 0;
+  for (size_t i = 0; i < gs.size(); ++i) n->grad_sb.start[i + 1] = n->grad_sb.start[i] + cdiv((int64_t)gs[i].rows * gs[i].cols, 256);
   HMP_HIP(hipMalloc(&n->d_pack_segs, ps.size() * sizeof(PackSeg)));
   HMP_HIP(hipMalloc(&n->d_pack_row_start, prs.size() * sizeof(int64_t)));
   HMP_HIP(hipMalloc(&n->d_grad_segs, gs.size() * sizeof(GradSeg)));
@@ -694,7 +703,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   {
     Scope sc(n, KC_PACK, side);
-    HMP_TRY(pack_launch(n->d_pack_segs, n->n_pack, n->max_pack_rows, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
+    HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
   }
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
@@ -925,7 +934,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   {
     Scope sc(n, KC_GRAD_REDUCE, st);
     const int64_t na = n->spec.n_active_params;
-    HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->n_grad, n->max_grad_elems, n->dyn, n->d_slabs, d_params, d_grads,
+    HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->grad_sb, n->dyn, n->d_slabs, d_params, d_grads,
                                n->fin_loss ? n->d_row_lv : nullptr, b->n_out, d_grads + na, n->d_state, st));
     n->fin_loss = false;
   }

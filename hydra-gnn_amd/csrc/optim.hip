@@ -151,11 +151,13 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(DropCfg cfg, int n_ro
 // reads its segment descriptor once and writes 4 packed rows (64 lanes per row).  Block (0,0) also starts the step:
 // it bumps the device step counter that dropout and Adam read later in the same step.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ segs, const float* __restrict__ params,
+__global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ segs, const SegBlocks sb, const float* __restrict__ params,
                                                    float* __restrict__ packed, NetState* step_state) {
-  if (step_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_state->step += 1;
-  const PackSeg S = segs[blockIdx.y];
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (step_state && blockIdx.x == 0 && threadIdx.x == 0) step_state->step += 1;
+  int si = 0;
+  while (si + 1 < sb.n && (int)blockIdx.x >= sb.start[si + 1]) ++si;  // wave-uniform scan of the kernarg table
+  const PackSeg S = segs[si];
+  const int r = ((int)blockIdx.x - sb.start[si]) * 4 + (threadIdx.x >> 6);
   if (r >= S.rows_pad) return;
   float* dst = packed + S.dst + (int64_t)r * S.ld_dst;
   for (int c = threadIdx.x & 63; c < S.ld_dst; c += 64) {
@@ -179,10 +181,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ s
   }
 }
 
-int pack_launch(const PackSeg* d_segs, int n_segs, int max_rows_pad, const float* d_params, float* d_packed, NetState* step_state,
-                hipStream_t st) {
-  if (n_segs == 0 || max_rows_pad == 0) return HMP_OK;
-  hipLaunchKernelGGL(pack_kernel, dim3(cdiv(max_rows_pad, 4), n_segs), dim3(256), 0, st, d_segs, d_params, d_packed, step_state);
+int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, NetState* step_state, hipStream_t st) {
+  if (sb.n == 0 || sb.start[sb.n] == 0) return HMP_OK;
+  hipLaunchKernelGGL(pack_kernel, dim3(sb.start[sb.n]), dim3(256), 0, st, d_segs, sb, d_params, d_packed, step_state);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
@@ -192,13 +193,17 @@ int pack_launch(const PackSeg* d_segs, int n_segs, int max_rows_pad, const float
 // grid = (element chunks of 1024, segments).  Block (0,0) additionally sums the per-row {loss, valid} pairs of the
 // loss kernel in fixed order into out2 = {loss_sum, count} (the tail of the flat gradient buffer).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, const GradReduceDyn dyn,
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, const SegBlocks sb, const GradReduceDyn dyn,
                                                           const float* __restrict__ slabs, const float* __restrict__ params,
                                                           float* __restrict__ grads, const float* __restrict__ row_lv, int n_lv_rows,
                                                           float* __restrict__ out2, NetState* state) {
-  const GradSeg& S = segs[blockIdx.y];
+  int si = 0;
+  while (si + 1 < sb.n && (int)blockIdx.x >= sb.start[si + 1]) ++si;
+  const GradSeg& S = segs[si];
   const int64_t n_el = (int64_t)S.rows * S.cols;
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n_el && i < (int64_t)(blockIdx.x + 1) * 1024; i += 256) {
+  {
+    const int64_t i = (int64_t)((int)blockIdx.x - sb.start[si]) * 256 + threadIdx.x;
+    if (i < n_el) {
     const int r = (int)(i / S.cols), c = (int)(i % S.cols);
     float total = 0.f;
     for (int ti = 0; ti < S.n_terms; ++ti) {
@@ -239,8 +244,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
       total += v * T.scale;
     }
     grads[S.dst + i] = total;
+    }
   }
-  if (row_lv != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (row_lv != nullptr && blockIdx.x == 0) {
     __shared__ float sl[256], sv[256];
     float l = 0.f, v = 0.f;
     for (int r = threadIdx.x; r < n_lv_rows; r += 256) { l += row_lv[2 * r]; v += row_lv[2 * r + 1]; }
@@ -259,12 +265,11 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
   }
 }
 
-int grad_reduce_launch(const GradSeg* d_segs, int n_segs, int64_t max_elems, const GradReduceDyn& dyn, const float* d_slabs,
+int grad_reduce_launch(const GradSeg* d_segs, const SegBlocks& sb, const GradReduceDyn& dyn, const float* d_slabs,
                        const float* d_params, float* d_grads, const float* row_lv, int n_lv_rows, float* out2, NetState* state,
                        hipStream_t st) {
-  if (n_segs == 0) return HMP_OK;
-  const int gx = (int)(max_elems > 0 ? cdiv(max_elems, 1024) : 1);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(gx, n_segs), dim3(256), 0, st, d_segs, dyn, d_slabs, d_params, d_grads, row_lv,
+  if (sb.n == 0 || sb.start[sb.n] == 0) return HMP_OK;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(sb.start[sb.n]), dim3(256), 0, st, d_segs, sb, dyn, d_slabs, d_params, d_grads, row_lv,
                      n_lv_rows, out2, state);
   HMP_LAUNCH_CHECK();
   return HMP_OK;

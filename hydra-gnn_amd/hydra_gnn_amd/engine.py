@@ -435,8 +435,9 @@ class TrainStep:
             with torch.cuda.stream(self._stream):
                 st = _lib.stream_ptr()
                 _lib.check(net._lib.hmp_graph_launch(ga, st))
-                self._all_reduce()
-                _lib.check(net._lib.hmp_graph_launch(gb, st))
+                if gb is not None:  # data parallel: the all-reduce sits between the two captured phases
+                    self._all_reduce()
+                    _lib.check(net._lib.hmp_graph_launch(gb, st))
             cur.wait_stream(self._stream)
 
     def _capture(self, h, key) -> None:
@@ -448,22 +449,29 @@ class TrainStep:
         with torch.cuda.stream(self._stream):
             st = _lib.stream_ptr()
             ga, gb = C.c_void_p(), C.c_void_p()
+            single = self._world() == 1  # no collective between the phases: ONE graph launch per step
             _lib.check(net._lib.hmp_graph_begin(st))
             try:
                 self._phase_a(h, st)
+                if single:
+                    self._phase_b(st)
             finally:
                 _lib.check(net._lib.hmp_graph_end(st, C.byref(ga)))
-            _lib.check(net._lib.hmp_graph_begin(st))
-            try:
-                self._phase_b(st)
-            finally:
-                _lib.check(net._lib.hmp_graph_end(st, C.byref(gb)))
+            if single:
+                gb = None
+            else:
+                _lib.check(net._lib.hmp_graph_begin(st))
+                try:
+                    self._phase_b(st)
+                finally:
+                    _lib.check(net._lib.hmp_graph_end(st, C.byref(gb)))
         self._graphs, self._key, self._holder = (ga, gb), key, h
 
     def _destroy_graphs(self) -> None:
         if self._graphs is not None:
             for g in self._graphs:
-                self.net._lib.hmp_graph_destroy(g)
+                if g is not None:
+                    self.net._lib.hmp_graph_destroy(g)
             self._graphs = None
 
     def __del__(self):
