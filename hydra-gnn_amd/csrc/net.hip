@@ -73,6 +73,7 @@ struct hmp_net {
   int64_t packed_floats, slab_floats;
   int out_dim, out_ld;
   bool any_gat = false;
+  bool pass0[HMP_MAX_NODE_TYPES] = {false};  // layer 1 reads the INPUT features of these types (pre_mp passthrough)
 
   // static device tables (owned)
   PackSeg* d_pack_segs = nullptr;
@@ -157,6 +158,11 @@ int build_layout(hmp_net* n) {
     for (int t = 0; t < n->T; ++t) {
       n->dim[l + 1][t] = Ls.out_dim[t];
       n->ld[l + 1][t] = fpad(Ls.out_dim[t]);
+      if (Ls.passthrough[t]) {
+        HMP_CHECK_ARG(l == 0 && n->L > 1, "net: passthrough node types are supported on the first layer only");
+        HMP_CHECK_ARG(Ls.out_dim[t] == S.in_dim[t], "net: passthrough type %d must keep its input width", t);
+        n->pass0[t] = true;
+      }
       Y.ncols[t] = 0;
       Y.roff[t] = -1;
       Y.n_in[t] = 0;
@@ -418,10 +424,15 @@ int build_tables(hmp_net* n) {
                 ps.size(), gs.size(), SEG_MAX);
   n->pack_sb.n = (int)ps.size();
   n->pack_sb.start[0] = 0;
-  for (size_t i = 0; i < ps.size(); ++i) n->pack_sb.start[i + 1] = n->pack_sb.start[i] + cdiv(ps[i].rows_pad, 4);
+  for (size_t i = 0; i < ps.size(); ++i)  // one wave per (row, 64-column chunk), 4 waves per block
+    n->pack_sb.start[i + 1] = n->pack_sb.start[i] + cdiv((int64_t)ps[i].rows_pad * cdiv(ps[i].ld_dst, 64), 4);
   n->grad_sb.n = (int)gs.size();
   n->grad_sb.start[0] = 0;
-  for (size_t i = 0; i < gs.size(); ++i) n->grad_sb.start[i + 1] = n->grad_sb.start[i] + cdiv((int64_t)gs[i].rows * gs[i].cols, 256);
+  for (size_t i = 0; i < gs.size(); ++i) {
+    const bool wave_mode = gs[i].n_terms == 1 && (gs[i].t[0].kind == GT_ATT_DOT || gs[i].t[0].kind == GT_ATT_DOT_T);
+    const int64_t el = (int64_t)gs[i].rows * gs[i].cols;
+    n->grad_sb.start[i + 1] = n->grad_sb.start[i] + cdiv(el, wave_mode ? 4 : 256);
+  }
   HMP_HIP(hipMalloc(&n->d_pack_segs, ps.size() * sizeof(PackSeg)));
   HMP_HIP(hipMalloc(&n->d_pack_row_start, prs.size() * sizeof(int64_t)));
   HMP_HIP(hipMalloc(&n->d_grad_segs, gs.size() * sizeof(GradSeg)));
@@ -462,7 +473,7 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
   for (int l = 0; l <= n->L; ++l)
     for (int t = 0; t < n->T; ++t) {
       n->H[l][t] = n->G[l][t] = nullptr;
-      if (l >= 1 && n->dim[l][t] > 0) {
+      if (l >= 1 && n->dim[l][t] > 0 && !(l == 1 && n->pass0[t])) {
         n->H[l][t] = (float*)take((size_t)cn[t] * n->ld[l][t] * 4);
         n->G[l][t] = (float*)take((size_t)cn[t] * n->ld[l][t] * 4);
       }
@@ -630,7 +641,8 @@ int check_batch(const hmp_net* n, const hmp_batch* b) {
   const hmp_net_spec& S = n->spec;
   for (int t = 0; t < n->T; ++t) {
     HMP_CHECK_ARG(b->n_nodes[t] >= 0 && b->n_nodes[t] <= n->cap_nodes[t], "batch: node type %d has %d nodes, capacity %d", t, b->n_nodes[t], n->cap_nodes[t]);
-    if (n->lay[0].ncols[t] > 0 && b->n_nodes[t] > 0)
+    const bool reads_x = n->lay[0].ncols[t] > 0 || (n->pass0[t] && n->lay[1].ncols[t] > 0);
+    if (reads_x && b->n_nodes[t] > 0)
       HMP_CHECK_ARG(b->d_x[t] != nullptr && b->ldx[t] >= n->dim[0][t], "batch: node type %d features missing or ld < %d", t, n->dim[0][t]);
   }
   for (int e = 0; e < n->ET; ++e) {
@@ -674,8 +686,9 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
   return plan_launch(pb, &n->d_state->status, st);
 }
 
-const float* h_ptr(const hmp_net* n, int l, int t) { return l == 0 ? n->batch.d_x[t] : n->H[l][t]; }
-int h_ld(const hmp_net* n, int l, int t) { return l == 0 ? n->batch.ldx[t] : n->ld[l][t]; }
+inline bool is_input(const hmp_net* n, int l, int t) { return l == 0 || (l == 1 && n->pass0[t]); }
+const float* h_ptr(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.d_x[t] : n->H[l][t]; }
+int h_ld(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.ldx[t] : n->ld[l][t]; }
 
 // launches a list of GEMM problems in groups of GEMM_MAX_PROB; ksplit_out receives the split of each problem
 int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out) {

@@ -157,10 +157,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ s
   int si = 0;
   while (si + 1 < sb.n && (int)blockIdx.x >= sb.start[si + 1]) ++si;  // wave-uniform scan of the kernarg table
   const PackSeg S = segs[si];
-  const int r = ((int)blockIdx.x - sb.start[si]) * 4 + (threadIdx.x >> 6);
+  // one wavefront per (packed row, 64-column chunk): the attention folds (a C-long dot per element) get as many
+  // wavefronts as the plain copies instead of one block looping over everything
+  const int chunks = (S.ld_dst + 63) >> 6;
+  const int item = ((int)blockIdx.x - sb.start[si]) * 4 + (threadIdx.x >> 6);
+  const int r = item / chunks;
   if (r >= S.rows_pad) return;
   float* dst = packed + S.dst + (int64_t)r * S.ld_dst;
-  for (int c = threadIdx.x & 63; c < S.ld_dst; c += 64) {
+  {
+    const int c = (item % chunks) * 64 + (threadIdx.x & 63);
+    if (c >= S.ld_dst) return;
     float v = 0.f;
     if (S.kind == PACK_SUM) {
       if (r < S.rows && c < S.cols)
@@ -201,7 +207,36 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
   while (si + 1 < sb.n && (int)blockIdx.x >= sb.start[si + 1]) ++si;
   const GradSeg& S = segs[si];
   const int64_t n_el = (int64_t)S.rows * S.cols;
-  {
+  if (S.n_terms == 1 && (S.t[0].kind == GT_ATT_DOT || S.t[0].kind == GT_ATT_DOT_T)) {
+    // attention-vector gradients are long dot products: one WAVEFRONT per element, lanes over the reduction index
+    const GradTerm& T = S.t[0];
+    const int64_t r = (int64_t)((int)blockIdx.x - sb.start[si]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r < n_el) {
+      const int ns = dyn.n_slabs[T.slab_id];
+      const int64_t stride = dyn.slab_stride[T.slab_id];
+      const float* w = params + T.w + r * T.ldw;
+      float part = 0.f;
+      if (T.kind == GT_ATT_DOT) {
+        const float* src = slabs + T.src + (int64_t)(r / T.C) * T.ld;
+        for (int f = lane; f < T.inner; f += 64) {
+          float s = 0.f;
+          for (int z = 0; z < ns; ++z) s += src[z * stride + f];
+          part += s * w[f];
+        }
+      } else {
+        const float* base = slabs + T.src + (r / T.C);
+        for (int d = lane; d < T.inner; d += 64) {
+          float s = 0.f;
+          for (int z = 0; z < ns; ++z) s += base[z * stride + (int64_t)d * T.ld];
+          part += s * w[d];
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+      if (lane == 0) grads[S.dst + r] = part * T.scale;
+    }
+  } else {
     const int64_t i = (int64_t)((int)blockIdx.x - sb.start[si]) * 256 + threadIdx.x;
     if (i < n_el) {
     const int r = (int)(i / S.cols), c = (int)(i % S.cols);

@@ -51,6 +51,7 @@ class LayerSpec(C.Structure):
     _fields_ = [
         ("n_convs", C.c_int32), ("act", C.c_int32), ("dropout", C.c_float), ("group_mean", C.c_int32),
         ("out_dim", C.c_int32 * MAX_NODE_TYPES),
+        ("passthrough", C.c_int32 * MAX_NODE_TYPES),
         ("convs", ConvSpec * MAX_CONVS),
     ]
 

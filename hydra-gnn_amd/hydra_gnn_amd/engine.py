@@ -37,8 +37,11 @@ class ConvDesc:
 
 
 class LayerDesc:
-    def __init__(self, convs: List[ConvDesc], out_dims: Dict[str, int], act: int, dropout: float, group_mean: bool = False):
+    def __init__(self, convs: List[ConvDesc], out_dims: Dict[str, int], act: int, dropout: float, group_mean: bool = False,
+                 passthrough: Sequence[str] = ()):
         self.convs, self.out_dims, self.act, self.dropout, self.group_mean = convs, out_dims, act, dropout, group_mean
+        # first layer only: node types whose input features stay visible to the next layer (`x_dict.update(pre_mp(..))`)
+        self.passthrough = list(passthrough)
 
 
 def _require_cuda(t: torch.Tensor, what: str) -> None:
@@ -100,6 +103,7 @@ class NativeNet:
                 conv.active = t in needed
                 if conv.active:
                     nxt.update((s, t))
+            nxt.update(t for t in layer.passthrough if t in needed)
             needed = nxt
 
     def _layout_params(self) -> None:
@@ -162,6 +166,7 @@ class NativeNet:
             ls.n_convs, ls.act, ls.dropout, ls.group_mean = len(layer.convs), layer.act, float(layer.dropout), int(layer.group_mean)
             for t, i in nt.items():
                 ls.out_dim[i] = int(layer.out_dims.get(t, 0))
+                ls.passthrough[i] = int(t in layer.passthrough)
             for c, conv in enumerate(layer.convs):
                 cs = ls.convs[c]
                 cs.kind, cs.edge_type = conv.kind, et[conv.edge_type]
@@ -372,8 +377,10 @@ class TrainStep:
 
     def __init__(self, net: NativeNet, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignored_label: int = 25, seed: int = 0, training: bool = True, use_graph: bool = True,
-                 process_group=None):
+                 process_group=None, force_collective: bool = False):
         self.net = net
+        # run the data-parallel launch structure (two graphs around one all-reduce) even with a single rank
+        self.force_collective = bool(force_collective)
         self.args = _lib.TrainArgs(lr, betas[0], betas[1], eps, weight_decay, ignored_label, seed, int(training))
         self.use_graph = use_graph
         self.pg = process_group
@@ -396,10 +403,11 @@ class TrainStep:
         return dist.get_world_size(self.pg if self.pg is not True else None)
 
     def _all_reduce(self) -> None:
-        if self._world() > 1:
+        if self._world() > 1 or self.force_collective:
             from . import parallel
 
-            parallel.allreduce_flat(self.grads, self.net.n_active, group=None if self.pg is True else self.pg)
+            parallel.allreduce_flat(self.grads, self.net.n_active, group=None if self.pg is True else self.pg,
+                                    force=self.force_collective)
 
     def _phase_a(self, h, st):
         net = self.net
@@ -449,7 +457,7 @@ class TrainStep:
         with torch.cuda.stream(self._stream):
             st = _lib.stream_ptr()
             ga, gb = C.c_void_p(), C.c_void_p()
-            single = self._world() == 1  # no collective between the phases: ONE graph launch per step
+            single = self._world() == 1 and not self.force_collective  # no collective between the phases: ONE graph per step
             _lib.check(net._lib.hmp_graph_begin(st))
             try:
                 self._phase_a(h, st)

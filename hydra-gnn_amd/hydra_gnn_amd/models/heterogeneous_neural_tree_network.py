@@ -13,7 +13,8 @@ import torch
 import torch.nn as nn
 
 from ..data import HTREE_EDGE_TYPES, HTREE_INIT_EDGE_TYPES, HTREE_NODE_TYPES
-from ..engine import NativeNet
+from ..engine import LayerDesc, NativeNet
+from .._lib import ACT_NONE
 from .heterogeneous_network import _NativeModule, _hetero_layers
 from .utils import GATConv, HeteroConv, build_GAT_hetero_conv, build_hetero_conv
 
@@ -93,13 +94,23 @@ class HeterogeneousNeuralTreeNetwork(_NativeModule):
         self._init_native()
 
     def _build_native(self) -> NativeNet:
-        if self.pre_mp is not None:
-            raise NotImplementedError("pre_mp clique initialisation is not wired into the native program yet "
-                                      "(set disable_initialization=True as every shipped H-tree config does)")
-        node_types = list(HTREE_NODE_TYPES) + ["room_virtual"]
-        in_dims = {t: self.input_dim_dict[t] for t in HTREE_NODE_TYPES}
-        return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + [POOL_EDGE_TYPE], _hetero_layers(self, node_types),
-                         readout="room", pool_edge_type=POOL_EDGE_TYPE, count_types=["room_virtual"])
+        layers = _hetero_layers(self, HTREE_NODE_TYPES)
+        if self.pre_mp is None:
+            node_types = list(HTREE_NODE_TYPES) + ["room_virtual"]
+            in_dims = {t: self.input_dim_dict[t] for t in HTREE_NODE_TYPES}
+            return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + [POOL_EDGE_TYPE], layers,
+                             readout="room", pool_edge_type=POOL_EDGE_TYPE, count_types=["room_virtual"])
+        # pre_mp (reference :92-103,158-159) = one more GAT layer in front: the virtual nodes (copies of the scene-graph
+        # nodes) write the clique features, the leaves keep theirs (`x_dict.update(...)` -> passthrough)
+        convs = [self.pre_mp.conv(et).desc(et) for et in self.pre_mp.edge_types]
+        out_dims = {et[2]: self.input_dim_dict[et[2]] for et in self.pre_mp.edge_types}
+        leaves = [t for t in HTREE_NODE_TYPES if t not in out_dims]
+        out_dims.update({t: self.input_dim_dict[t] for t in leaves})
+        init = LayerDesc(convs, out_dims, ACT_NONE, 0.0, group_mean=(self.pre_mp.aggr == "mean"), passthrough=leaves)
+        node_types = list(HTREE_NODE_TYPES) + ["room_virtual", "object_virtual"]
+        in_dims = {t: self.input_dim_dict[t] for t in node_types}
+        return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + [POOL_EDGE_TYPE] + list(HTREE_INIT_EDGE_TYPES),
+                         [init] + layers, readout="room", pool_edge_type=POOL_EDGE_TYPE)
 
     def forward(self, data):
         out = self._run(data)

@@ -39,12 +39,13 @@ def shard_graphs_balanced(edge_counts: Sequence[int], rank: int, world: int) -> 
     return sorted(mine)
 
 
-def allreduce_flat(buf: torch.Tensor, n_active: int, group=None) -> torch.Tensor:
-    """Sum ``buf[0 : n_active + 2]`` over the ranks in place (one collective) and return that slice."""
+def allreduce_flat(buf: torch.Tensor, n_active: int, group=None, force: bool = False) -> torch.Tensor:
+    """Sum ``buf[0 : n_active + 2]`` over the ranks in place (one collective) and return that slice.
+    ``force`` issues the collective even in a 1-rank group (exercises the RCCL path on a single GPU)."""
     import torch.distributed as dist
 
     view = buf[: n_active + 2]
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
     return view
 

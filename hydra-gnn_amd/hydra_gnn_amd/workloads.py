@@ -173,7 +173,7 @@ def stanford_like_graph(rng: np.random.Generator, n_nodes: Optional[int] = None)
 # config 4: H-tree (Neural-Tree) batches from the committed topology fixture (tests/golden/htree_topologies.npz, made by
 # tests/golden/make_htree_fixture.py with the reference's junction-tree code)
 # ---------------------------------------------------------------------------------------------------------------------
-from .data import HTREE_EDGE_TYPES, HTREE_NODE_TYPES  # noqa: E402
+from .data import HTREE_EDGE_TYPES, HTREE_INIT_EDGE_TYPES, HTREE_NODE_TYPES  # noqa: E402
 
 HTREE_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
                              "htree_topologies.npz")
@@ -196,9 +196,21 @@ def htree_graph(npz, gi: int, rng: np.random.Generator) -> HeteroData:
     for k, et in enumerate(HTREE_EDGE_TYPES):
         g[et].edge_index = torch.from_numpy(npz[f"g{gi}_e{k}"].astype(np.int64).reshape(2, -1))
     room_orig = npz[f"g{gi}_room_orig"].astype(np.int64)
+    obj_orig = npz[f"g{gi}_object_orig"].astype(np.int64)
+    n_objects = int(npz[f"g{gi}_n_objects"])
     g["room", "r_to_rv", "room_virtual"].edge_index = torch.from_numpy(np.stack([np.arange(len(room_orig)), room_orig], 0))
-    g["room_virtual"].num_nodes = n_rooms
+    g["object", "o_to_ov", "object_virtual"].edge_index = torch.from_numpy(np.stack([np.arange(len(obj_orig)), obj_orig], 0))
+    # virtual nodes = copies of the original scene-graph nodes (construct.py:313-346): they carry x (read by pre_mp) and y
+    g["room_virtual"].x = torch.from_numpy(np.concatenate([rng.normal(0.0, 5.0, size=(n_rooms, 3)),
+                                                            rng.uniform(0.1, 2.0, size=(n_rooms, 3))], 1).astype(np.float32))
+    g["object_virtual"].x = torch.from_numpy(np.concatenate([rng.normal(0.0, 5.0, size=(n_objects, 3)),
+                                                              rng.uniform(0.1, 2.0, size=(n_objects, 3)),
+                                                              rng.normal(0.0, 0.15, size=(n_objects, 300))], 1).astype(np.float32))
     g["room_virtual"].y = torch.from_numpy(rng.integers(0, NUM_ROOM_LABELS, size=n_rooms).astype(np.int64))
+    for k, et in enumerate(HTREE_INIT_EDGE_TYPES):
+        key = f"g{gi}_i{k}"
+        if key in npz:
+            g[et].edge_index = torch.from_numpy(npz[key].astype(np.int64).reshape(2, -1))
     return g
 
 

@@ -185,6 +185,9 @@ typedef struct hmp_layer_spec {
   float dropout;       /* feature dropout after the activation (training only) */
   int32_t group_mean;  /* HeteroConv aggr: 0 = sum, 1 = mean over the convs reaching a node type */
   int32_t out_dim[HMP_MAX_NODE_TYPES]; /* output width per node type (0 = type receives nothing) */
+  /* layer 0 only: node types the layer does not produce but whose INPUT features stay visible to layer 1
+   * (`x_dict.update(pre_mp(...))`, heterogeneous_neural_tree_network.py:158-159); out_dim must equal in_dim */
+  int32_t passthrough[HMP_MAX_NODE_TYPES];
   hmp_conv_spec convs[HMP_MAX_CONVS];
 } hmp_layer_spec;
 

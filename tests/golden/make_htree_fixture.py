@@ -132,7 +132,18 @@ def typed_arrays(G, ht):
     for u, v in ht.to_directed().edges:
         et = (ht.nodes[u]["node_type"], ht.nodes[v]["node_type"])
         edges[et].append((local[u], local[v]))
-    return per_type, leaf_orig, edges
+    # init edges virtual -> clique (construct.py:364-369): one per member of the clique; the virtual index is the member's
+    # original index inside its type (virtual nodes are ordered objects then rooms, construct.py:338-346)
+    init = {"ov_to_or": [], "rv_to_or": [], "rv_to_rr": []}
+    for t, key_o, key_r in (("object-room", "ov_to_or", "rv_to_or"), ("room-room", None, "rv_to_rr")):
+        for i in per_type[t]:
+            for member in ht.nodes[i]["clique_has"]:
+                if member < n_obj:
+                    assert key_o is not None
+                    init[key_o].append((member, local[i]))
+                else:
+                    init[key_r].append((member - n_obj, local[i]))
+    return per_type, leaf_orig, edges, init
 
 
 def main():
@@ -147,7 +158,9 @@ def main():
         ht = build_htree(G)
         # NB not necessarily a forest: networkx's junction_tree shares one sepset node between all cliques that
         # intersect in the same set, and the reference projects that bipartite graph onto the cliques
-        per_type, leaf_orig, edges = typed_arrays(G, ht)
+        per_type, leaf_orig, edges, init = typed_arrays(G, ht)
+        for k, name in enumerate(("ov_to_or", "rv_to_or", "rv_to_rr")):
+            out[f"g{gi}_i{k}"] = np.array(init[name], dtype=np.int32).reshape(-1, 2).T
         out[f"g{gi}_n_objects"] = np.int32(g["objects"].num_nodes)
         out[f"g{gi}_n_rooms"] = np.int32(g["rooms"].num_nodes)
         out[f"g{gi}_counts"] = np.array([len(per_type[t]) for t in NODE_TYPES], dtype=np.int32)

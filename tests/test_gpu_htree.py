@@ -65,6 +65,29 @@ def test_htree_network_parity(hidden, layers, block):
     compare(net, o64, pred, pred_ref, batch["room_virtual"].y)
 
 
+@pytest.mark.parametrize("block,hidden,layers", [("GraphSAGE", 32, 3), ("GAT", 16, 2)])
+def test_htree_network_with_pre_mp_initialisation_parity(block, hidden, layers):
+    """disable_initialization=False: the GAT `pre_mp` HeteroConv(aggr='mean') over the 3 init edge types rewrites the
+    clique features from the virtual nodes before message passing (reference :92-103,158-159)."""
+    torch.manual_seed(1)
+    kw = dict(input_dim_dict=HT_DIMS, output_dim=26, conv_block=block, hidden_dim=hidden, num_layers=layers,
+              GAT_hidden_dims=[hidden] * (layers - 1), GAT_heads=[2] * layers, GAT_concats=[True] * (layers - 1) + [False],
+              disable_initialization=False, dropout=0.0)
+    ora = omodels.HeterogeneousNeuralTreeNetwork(**kw)
+    with torch.no_grad():
+        for n_, p_ in ora.named_parameters():
+            if n_.endswith(".bias") and "pre_mp" in n_:
+                p_.uniform_(-0.2, 0.2)
+    net = HeterogeneousNeuralTreeNetwork(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net = net.to(DEV).eval()
+    batch = workloads.htree_batch(5, seed=33)
+    o64 = copy.deepcopy(ora).double().eval()
+    pred_ref = o64(to64(batch))
+    pred = net(batch.to(DEV))
+    compare(net, o64, pred, pred_ref, batch["room_virtual"].y)
+
+
 def test_htree_fused_train_step_learns():
     torch.manual_seed(0)
     net = HeterogeneousNeuralTreeNetwork(HT_DIMS, output_dim=26, conv_block="GraphSAGE", hidden_dim=64, num_layers=4,
