@@ -306,6 +306,19 @@ def main():
                                    "unit": "GB/s", "frac": round(d["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
                                    "avg_launch_us": d["avg_us"]}
             out["roofline_all"] = table
+            # HBM traffic of the dominant family from the committed PMC passes of this same command (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_summary.py)
+            import glob
+
+            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_cfg{args.config}.json")))
+            if pmc:
+                key = {"gemm": "gemm_kernel", "agg_fwd": "agg_fwd_kernel", "agg_bwd": "agg_bwd_kernel",
+                       "gat_fwd": "gat_fwd_kernel", "gat_bwd": "gat_bwd"}[dom]
+                ks = [v for k, v in json.load(open(pmc[-1]))["kernels"].items() if key in k]
+                nd = sum(v["dispatches"] for v in ks)
+                if nd:
+                    out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in ks) / nd)
+                    out["roofline"]["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
 
     # ---- CPU baseline: the oracle (op-for-op PyG restatement) on the host cores, bounded sample -------------------------
     if rank == 0 and not args.no_cpu_baseline:
