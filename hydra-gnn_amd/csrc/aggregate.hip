@@ -40,94 +40,84 @@ struct Acc<1> {
   __device__ __forceinline__ float& at(int) { return v; }
 };
 
-// sum_{k in [b,e)} x[col[k]][c .. c+VEC)   in edge order; NV column chunks per lane (stride GS*VEC)
+// sum_{k in [b,e)} x[col[k]][c .. c+VEC)   in edge order; NV column chunks per lane (stride GS*VEC).
+// Neighbours are processed in batches of UB = 8 (4 for wide rows) with NO tail loop: ids beyond the row are clamped to the
+// last valid entry (same address => cache hit) and masked at the add.  A row of degree <= 8 therefore costs three
+// dependent memory round trips (extent, ids, rows) instead of one per tail neighbour.
 template <int GS, int NV, int VEC>
 __device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __restrict__ x, int ld, const int* __restrict__ col,
                                            int b, int e, int c0, int F) {
-  int k = b;
-  for (; k + 4 <= e; k += 4) {
-    const int j0 = col[k], j1 = col[k + 1], j2 = col[k + 2], j3 = col[k + 3];
-    Acc<VEC> v0[NV], v1[NV], v2[NV], v3[NV];
+  constexpr int UB = (NV == 1) ? 8 : 4;
+  for (int k = b; k < e; k += UB) {
+    int j[UB];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int c = c0 + q * GS * VEC;
-      if (c < F) {
-        v0[q].load(x + (int64_t)j0 * ld + c);
-        v1[q].load(x + (int64_t)j1 * ld + c);
-        v2[q].load(x + (int64_t)j2 * ld + c);
-        v3[q].load(x + (int64_t)j3 * ld + c);
+    for (int u = 0; u < UB; ++u) j[u] = col[min(k + u, e - 1)];
+    Acc<VEC> v[UB][NV];
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c = c0 + q * GS * VEC;
+        if (c < F) v[u][q].load(x + (int64_t)j[u] * ld + c);
       }
-    }
+    const int cnt = e - k;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int c = c0 + q * GS * VEC;
-      if (c < F) { acc[q].add(v0[q]); acc[q].add(v1[q]); acc[q].add(v2[q]); acc[q].add(v3[q]); }
-    }
-  }
-  for (; k < e; ++k) {
-    const int j = col[k];
+    for (int u = 0; u < UB; ++u)
+      if (u < cnt) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int c = c0 + q * GS * VEC;
-      if (c < F) { Acc<VEC> v; v.load(x + (int64_t)j * ld + c); acc[q].add(v); }
-    }
+        for (int q = 0; q < NV; ++q) {
+          const int c = c0 + q * GS * VEC;
+          if (c < F) acc[q].add(v[u][q]);
+        }
+      }
   }
 }
 
-// sum_k g[tcol[k]][c..] / max(deg(tcol[k]),1)  (backward of the mean: every edge carries 1/deg(dst))
-// `degf` (float max(deg,1) per destination, written by the plan) removes the two dependent rowptr loads per edge;
-// four edges are in flight at a time (ids, then degrees + rows, then the ordered adds).
+// sum_k g[tcol[k]][c..] / max(deg(tcol[k]),1)  (backward of the mean: every edge carries 1/deg(dst)).
+// `degf` (float max(deg,1) per destination, written by the plan) removes the two dependent rowptr loads per edge; without
+// it (unit entry point) the degree is derived from rowptr.  Same clamped batches as gather_sum.
 template <int GS, int NV, int VEC>
 __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* __restrict__ g, int ld, const int* __restrict__ tcol,
                                              const int* __restrict__ rowptr, const float* __restrict__ degf, int mean, int b, int e,
                                              int c0, int F) {
-  int k = b;
-  if (degf != nullptr || !mean) {
-    for (; k + 4 <= e; k += 4) {
-      const int i0 = tcol[k], i1 = tcol[k + 1], i2 = tcol[k + 2], i3 = tcol[k + 3];
-      float d0 = 1.f, d1 = 1.f, d2 = 1.f, d3 = 1.f;
-      if (mean) { d0 = degf[i0]; d1 = degf[i1]; d2 = degf[i2]; d3 = degf[i3]; }
-      Acc<VEC> v0[NV], v1[NV], v2[NV], v3[NV];
+  constexpr int UB = (NV == 1) ? 8 : 4;
+  for (int k = b; k < e; k += UB) {
+    int i[UB];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int c = c0 + q * GS * VEC;
-        if (c < F) {
-          v0[q].load(g + (int64_t)i0 * ld + c);
-          v1[q].load(g + (int64_t)i1 * ld + c);
-          v2[q].load(g + (int64_t)i2 * ld + c);
-          v3[q].load(g + (int64_t)i3 * ld + c);
-        }
-      }
+    for (int u = 0; u < UB; ++u) i[u] = tcol[min(k + u, e - 1)];
+    float d[UB];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int c = c0 + q * GS * VEC;
-        if (c < F) {
-          if (mean) { acc[q].add_div(v0[q], d0); acc[q].add_div(v1[q], d1); acc[q].add_div(v2[q], d2); acc[q].add_div(v3[q], d3); }
-          else { acc[q].add(v0[q]); acc[q].add(v1[q]); acc[q].add(v2[q]); acc[q].add(v3[q]); }
+    for (int u = 0; u < UB; ++u) {
+      d[u] = 1.f;
+      if (mean) {
+        if (degf) {
+          d[u] = degf[i[u]];
+        } else {
+          const int deg = rowptr[i[u] + 1] - rowptr[i[u]];
+          d[u] = (float)(deg > 1 ? deg : 1);
         }
       }
     }
-  }
-  for (; k < e; ++k) {
-    const int i = tcol[k];
-    float d = 1.f;
-    if (mean) {
-      if (degf) {
-        d = degf[i];
-      } else {
-        const int deg = rowptr[i + 1] - rowptr[i];
-        d = (float)(deg > 1 ? deg : 1);
-      }
-    }
+    Acc<VEC> v[UB][NV];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int c = c0 + q * GS * VEC;
-      if (c < F) {
-        Acc<VEC> v;
-        v.load(g + (int64_t)i * ld + c);
-        if (mean) acc[q].add_div(v, d); else acc[q].add(v);
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c = c0 + q * GS * VEC;
+        if (c < F) v[u][q].load(g + (int64_t)i[u] * ld + c);
       }
-    }
+    const int cnt = e - k;
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (u < cnt) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int c = c0 + q * GS * VEC;
+          if (c < F) {
+            if (mean) acc[q].add_div(v[u][q], d[u]); else acc[q].add(v[u][q]);
+          }
+        }
+      }
   }
 }
 
@@ -172,18 +162,10 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
 }
 
 // ----- fused SAGE layer aggregation -----------------------------------------------------------------
-// out[t][i] = dropout(act( zroot[i] + bias + sum_e mean_{k in N_e(i)} z_e[col_k] ))
+// out[t][i] = dropout(act( zroot[i] + bias + sum_e mean_{k in N_e(i)} z_e[col_k] ))   (one row group, result also in `tot`)
 template <int GS, int NV>
-__global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
+__device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int c0, Acc<4> (&tot)[NV]) {
   constexpr int VEC = 4;
-  int ti = 0;
-  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
-  const AggDst& D = a.d[ti];
-  const int rpb = 256 / GS;
-  const int row = (blockIdx.x - D.block_start) * rpb + threadIdx.x / GS;
-  if (row >= D.n_rows) return;
-  const int c0 = (threadIdx.x % GS) * VEC;
-  Acc<VEC> tot[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c = c0 + q * GS * VEC;
@@ -210,7 +192,7 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q].zero();
     gather_sum<GS, NV, VEC>(acc, I.z + I.coff, I.ldz, I.col, b, e, c0, D.F);
-    const float d = a.mean ? (float)(e - b) : 1.f;
+    const float d = mean ? (float)(e - b) : 1.f;
 #pragma unroll
     for (int q = 0; q < NV; ++q) tot[q].add_div(acc[q], d);
   }
@@ -231,6 +213,79 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
       tot[q].at(i) = v;
     }
     tot[q].store(D.out + (int64_t)row * D.ldo + c);
+  }
+}
+
+template <int GS, int NV>
+__global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
+  int ti = 0;
+  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
+  const AggDst& D = a.d[ti];
+  const int rpb = 256 / GS;
+  const int row = (blockIdx.x - D.block_start) * rpb + threadIdx.x / GS;
+  if (row >= D.n_rows) return;
+  Acc<4> tot[NV];
+  agg_row<GS, NV>(D, a.mean, row, (threadIdx.x % GS) * 4, tot);
+}
+
+// ----- aggregation of layer l FUSED with the projection of layer l+1 --------------------------------------------
+// The projection Z[l+1][t] = H[l+1][t] * Wp[l+1][t]^T is row-local, so the block that has just aggregated 16 rows of
+// H[l+1][t] keeps them in LDS ([k][row] image, LD 17) and multiplies them on the matrix cores right away
+// (v_mfma_f32_16x16x4_f32: 16 rows x 16 packed columns per accumulator, exact fp32).  One kernel (and one ~4 us launch
+// floor, one cross-XCD hand-off of H) less per layer; H is still written to HBM for the backward pass.
+// Wp is read straight from L2 (it is <= 200 KB and shared by every block): lane (n, kq) loads 16 bytes
+// Wp[n0 + n][16 i + 4 kq .. +3] and feeds 4 MFMAs with them; the k order inside a 16-block is permuted identically
+// for both operands (k = 16 i + 4 kq + u at step u), which a sum over k does not care about.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int GS>
+__global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
+  constexpr int TM = 16, LDH = 17;
+  constexpr int RPP = 256 / GS;            // rows aggregated per pass
+  constexpr int NP = TM / RPP;             // passes (GS = 16: 1, 32: 2, 64: 4)
+  __shared__ float Hs[256 * LDH];
+  int ti = 0;
+  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
+  const AggDst& D = a.d[ti];
+  const int row0 = ((int)blockIdx.x - D.block_start) * TM;
+  const int c0 = (threadIdx.x % GS) * 4;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int m = p * RPP + threadIdx.x / GS;
+    const int row = row0 + m;
+    Acc<4> tot[1];
+    tot[0].zero();
+    if (row < D.n_rows) agg_row<GS, 1>(D, a.mean, row, c0, tot);
+    if (c0 < D.pK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Hs[(c0 + i) * LDH + m] = (c0 < D.F && row < D.n_rows) ? tot[0].at(i) : 0.f;
+    }
+  }
+  if (D.pw == nullptr) return;  // block-uniform: this node type is not read by the next layer
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int n_ct = (D.pncols + 15) >> 4;
+  for (int ct = w; ct < n_ct; ct += 4) {
+    const int col = ct * 16 + n;
+    const float* wrow = D.pw + (int64_t)min(col, D.pncols - 1) * D.pldw;  // clamped: padded columns are never stored
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < D.pK; kb += 16) {
+      const float4 bv = *reinterpret_cast<const float4*>(wrow + kb + 4 * kq);
+      const float* hp = Hs + (kb + 4 * kq) * LDH + n;  // A operand: row m = lane & 15 of the tile
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[0 * LDH], bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[1 * LDH], bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[2 * LDH], bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[3 * LDH], bv.w, acc, 0, 0, 0);
+    }
+    // D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+    if (col < D.pncols) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + kq * 4 + r;
+        if (row < D.n_rows) D.pz[(int64_t)row * D.pldz + col] = acc[r];
+      }
+    }
   }
 }
 
@@ -317,6 +372,33 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
 #define LAUNCH_FWD(GS_, NV_) hipLaunchKernelGGL((agg_fwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_FWD)
 #undef LAUNCH_FWD
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+int agg_proj_fwd_launch(AggArgs& a, hipStream_t st) {
+  int Fmax = 0, blocks = 0;
+  for (int i = 0; i < a.n; ++i) Fmax = a.d[i].F > Fmax ? a.d[i].F : Fmax;
+  if (a.n == 0 || Fmax == 0) return HMP_OK;
+  HMP_CHECK_ARG(Fmax <= 256, "agg_proj_fwd: row width %d > 256", Fmax);
+  int gs = 16;
+  while (gs < 64 && gs * 4 < Fmax) gs <<= 1;
+  for (int i = 0; i < a.n; ++i) {
+    AggDst& D = a.d[i];
+    HMP_CHECK_ARG((D.ldo & 3) == 0 && (D.F & 3) == 0, "agg_proj_fwd: widths must be padded to 4");
+    if (D.pw)
+      HMP_CHECK_ARG((D.pK & 15) == 0 && D.pK <= 256 && D.pK <= D.F && (D.pldw & 3) == 0 && D.pncols > 0,
+                    "agg_proj_fwd: projection K %d / ld %d not supported", D.pK, D.pldw);
+    D.block_start = blocks;
+    blocks += cdiv(D.n_rows, 16);
+  }
+  a.total_blocks = blocks;
+  if (blocks == 0) return HMP_OK;
+  switch (gs) {
+    case 16: hipLaunchKernelGGL((agg_proj_fwd_kernel<16>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((agg_proj_fwd_kernel<32>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((agg_proj_fwd_kernel<64>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

@@ -325,6 +325,8 @@ template <int WM, int WN, int BK>
 static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   int start = 0;
+  int all_tiles = 0;
+  for (int i = 0; i < gb.n; ++i) all_tiles += cdiv(gb.p[i].M, BM) * cdiv(gb.p[i].N, BN);
   for (int i = 0; i < gb.n; ++i) {
     GemmProblem& p = gb.p[i];
     p.tiles_m = cdiv(p.M, BM);
@@ -332,8 +334,8 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
     int tiles = p.tiles_m * p.tiles_n;
     int ks = 1;
     if (want_split && tiles > 0) {
-      // aim at ~1024 workgroups overall; every slab gets >= 1 full K stage
-      ks = 1024 / (tiles * gb.n);
+      // aim at ~1024 workgroups over the whole launch; every slab gets >= 1 full K stage
+      ks = 1024 / (all_tiles > 0 ? all_tiles : 1);
       int max_by_k = cdiv(p.K, BK);
       if (ks > max_by_k) ks = max_by_k;
       if (ks > max_slabs) ks = max_slabs;

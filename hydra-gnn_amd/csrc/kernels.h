@@ -86,6 +86,10 @@ struct AggDst {
   int drop_on;
   DropCfg drop;
   int block_start;
+  // fused projection of the NEXT layer (agg_proj_fwd_launch): Z[l+1][t] = out * pw^T, pw = Wp[l+1][t] [pncols][pldw]
+  const float* pw;  // null: this node type is not read by the next layer
+  float* pz;
+  int pldw, pldz, pncols, pK;
   AggIn in[AGG_MAX_IN];
 };
 struct AggArgs {
@@ -95,6 +99,8 @@ struct AggArgs {
   AggDst d[HMP_MAX_NODE_TYPES];
 };
 int agg_fwd_launch(AggArgs& a, hipStream_t st);
+// same + next-layer projection per 16-row tile (requires F <= 256, pK % 16 == 0, pK <= 256 for every entry with pw)
+int agg_proj_fwd_launch(AggArgs& a, hipStream_t st);
 
 struct TAggOut {
   const int* t_rowptr;

@@ -119,6 +119,8 @@ struct hmp_net {
 
   // parallel branches (side streams; under capture they become branches of the hipGraph)
   bool use_branches = false;
+  bool dw_branch = false;  // weight-gradient GEMMs per layer on a side stream instead of one merged launch
+  int dw_mode = -1;        // HMP_DW_BRANCH override (0 / 1), -1 = automatic
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t evs[32];
   int n_evs = 0, ev_i = 0;
@@ -718,11 +720,12 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     Scope sc(n, KC_PACK, side);
     HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
   }
+  bool z_done = false;
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
     st = (l == 0) ? side : main_st;
-    {  // grouped projection
+    if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
       Scope sc(n, KC_GEMM_FWD, st);
       std::vector<GemmProblem> ps;
       for (int s = 0; s < n->T; ++s) {
@@ -739,6 +742,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
       }
       HMP_TRY(gemm_many(ps, false, st, nullptr));
     }
+    z_done = false;
     if (l == 0) {
       HMP_TRY(run_plan(n, b, main_st));
       if (side != main_st) HMP_TRY(fork_to(n, side, main_st));  // join
@@ -811,6 +815,16 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     ld_gtop = n->ld[n->L][rt];
   }
   memset(&n->dyn, 0, sizeof(n->dyn));
+  {
+    // measured on MI355X (bench.py configs 2/3/4): below ~4k nodes per batch every kernel is launch-bound and one merged
+    // weight-gradient launch wins (+2.5 %); above, overlapping the per-layer launches with the backward chain wins
+    // (+4 % at 6k nodes, +10 % at 12k)
+    int total_nodes = 0;
+    for (int t = 0; t < n->T; ++t) total_nodes += b->n_nodes[t];
+    n->dw_branch = n->use_branches && (n->dw_mode >= 0 ? n->dw_mode == 1 : total_nodes > 4096);
+  }
+  std::vector<GemmProblem> wps;  // weight-gradient problems of all layers (merged mode)
+  std::vector<int> wids;
   for (int l = n->L - 1; l >= 0; --l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
@@ -854,9 +868,11 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       }
       HMP_TRY(agg_bwd_launch(a, st));
     }
-    // dZ[l] is complete: the weight-gradient GEMM of this layer leaves the critical path (side stream / graph branch)
+    // dZ[l] is complete.  Weight-gradient GEMMs: either ALL layers in one grouped split-K launch after the loop
+    // (default: one launch with ~1k workgroups instead of L launches, and no cross-queue fork per layer -- each fork
+    // costs ~5 us of dependency latency under graph replay), or per layer on a side stream (HMP_DW_BRANCH=1).
     hipStream_t wst = st;
-    if (n->use_branches) {
+    if (n->use_branches && n->dw_branch) {
       wst = n->side[1];
       HMP_TRY(fork_to(n, st, wst));
     }
@@ -888,9 +904,10 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       HMP_TRY(gemm_many(ps, false, st, nullptr));
     }
     {  // weight + bias gradient: dWp = dZ^T * [H | 1], split over node chunks (+ GAT: bias column sums, d V_edge)
-      Scope sc(n, KC_GEMM_BWD, wst);
-      std::vector<GemmProblem> ps;
-      std::vector<int> ids;
+      std::vector<GemmProblem> local_ps;
+      std::vector<int> local_ids;
+      std::vector<GemmProblem>& ps = n->dw_branch ? local_ps : wps;
+      std::vector<int>& ids = n->dw_branch ? local_ids : wids;
       auto add = [&](int sid, const GemmProblem& p) {
         n->dyn.slab_stride[sid] = (int)p.slab_stride;
         ids.push_back(sid);
@@ -938,12 +955,22 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           add(slab_id_v(l, c), p);
         }
       }
-      std::vector<int> ks;
-      HMP_TRY(gemm_many(ps, true, wst, &ks));
-      for (size_t i = 0; i < ids.size(); ++i) n->dyn.n_slabs[ids[i]] = (unsigned char)ks[i];
+      if (n->dw_branch) {
+        Scope sc(n, KC_GEMM_BWD, wst);
+        std::vector<int> ks;
+        HMP_TRY(gemm_many(ps, true, wst, &ks));
+        for (size_t i = 0; i < ids.size(); ++i) n->dyn.n_slabs[ids[i]] = (unsigned char)ks[i];
+      }
     }
   }
-  if (n->use_branches) HMP_TRY(fork_to(n, n->side[1], st));  // join the weight-gradient branch
+  if (n->dw_branch) {
+    if (n->use_branches) HMP_TRY(fork_to(n, n->side[1], st));  // join the weight-gradient branch
+  } else {
+    Scope sc(n, KC_GEMM_BWD, st);
+    std::vector<int> ks;
+    HMP_TRY(gemm_many(wps, true, st, &ks));
+    for (size_t i = 0; i < wids.size(); ++i) n->dyn.n_slabs[wids[i]] = (unsigned char)ks[i];
+  }
   {
     Scope sc(n, KC_GRAD_REDUCE, st);
     const int64_t na = n->spec.n_active_params;
@@ -975,6 +1002,8 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
       if (ok) n->n_evs = i + 1;
     }
     n->use_branches = ok && n->n_evs == 32;
+    const char* db = getenv("HMP_DW_BRANCH");
+    n->dw_mode = db ? (db[0] == '1' ? 1 : 0) : -1;  // -1: decide per batch (see backward_impl)
   }
   if (r != HMP_OK) {
     hmp_net_destroy(n);
