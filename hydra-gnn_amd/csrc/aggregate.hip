@@ -216,6 +216,51 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
   }
 }
 
+// Masked cross entropy of one output row held by its row group (lane = 4 consecutive logits): models/utils.py:143-148
+// with mask = label != ignored; writes the gradient of the SUM loss and the row's {loss, valid} pair.  The group
+// reductions are xor butterflies below GS, i.e. inside the (GS-aligned) row group.
+template <int GS>
+__device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, int row, int c0, Acc<4>& t) {
+  const int nc = D.ce_classes;
+  float v[4];
+  bool in[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    in[i] = c0 + i < nc;
+    v[i] = in[i] ? t.at(i) : -INFINITY;
+    m = fmaxf(m, v[i]);
+  }
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += in[i] ? expf(v[i] - m) : 0.f;
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float lse = m + logf(s);
+  const int64_t y = D.ce_labels[row];
+  const bool valid = (y != D.ce_ignored);
+  const bool bad = valid && (y < 0 || y >= nc);
+  const bool use = valid && !bad;
+  float ly = 0.f;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool hit = use && (int64_t)(c0 + i) == y;
+    if (hit) ly = v[i];
+    if (use && in[i]) (&g.x)[i] = expf(v[i] - lse) - (hit ? 1.f : 0.f);
+  }
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) ly += __shfl_xor(ly, o);
+  if (c0 < D.ce_ldg) *reinterpret_cast<float4*>(D.ce_grad + (int64_t)row * D.ce_ldg + c0) = g;
+  if ((threadIdx.x % GS) == 0) {
+    D.ce_row_lv[2 * row] = use ? (lse - ly) : 0.f;
+    D.ce_row_lv[2 * row + 1] = use ? 1.f : 0.f;
+    if (bad && state) atomicOr(&state->status, 2);
+  }
+}
+
 template <int GS, int NV>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   int ti = 0;
@@ -225,7 +270,11 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   const int row = (blockIdx.x - D.block_start) * rpb + threadIdx.x / GS;
   if (row >= D.n_rows) return;
   Acc<4> tot[NV];
-  agg_row<GS, NV>(D, a.mean, row, (threadIdx.x % GS) * 4, tot);
+  const int c0 = (threadIdx.x % GS) * 4;
+  agg_row<GS, NV>(D, a.mean, row, c0, tot);
+  if constexpr (NV == 1) {
+    if (D.ce_labels) ce_rowgroup<GS>(D, a.state, row, c0, tot[0]);
+  }
 }
 
 // ----- aggregation of layer l FUSED with the projection of layer l+1 --------------------------------------------
@@ -270,13 +319,20 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
     const int col = ct * 16 + n;
     const float* wrow = D.pw + (int64_t)min(col, D.pncols - 1) * D.pldw;  // clamped: padded columns are never stored
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < D.pK; kb += 16) {
-      const float4 bv = *reinterpret_cast<const float4*>(wrow + kb + 4 * kq);
-      const float* hp = Hs + (kb + 4 * kq) * LDH + n;  // A operand: row m = lane & 15 of the tile
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[0 * LDH], bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[1 * LDH], bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[2 * LDH], bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[3 * LDH], bv.w, acc, 0, 0, 0);
+    // 4 k-blocks of 16 per trip: the 4 (clamped) 16-byte weight loads are in flight together, then 16 MFMAs
+    for (int kb = 0; kb < D.pK; kb += 64) {
+      float4 bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bv[u] = *reinterpret_cast<const float4*>(wrow + min(kb + 16 * u, D.pK - 16) + 4 * kq);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (kb + 16 * u >= D.pK) break;
+        const float* hp = Hs + (kb + 16 * u + 4 * kq) * LDH + n;  // A operand: row m = lane & 15 of the tile
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[0 * LDH], bv[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[1 * LDH], bv[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[2 * LDH], bv[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[3 * LDH], bv[u].w, acc, 0, 0, 0);
+      }
     }
     // D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
     if (col < D.pncols) {
@@ -289,10 +345,33 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
   }
 }
 
+// fixed-order sum of the per-row {loss, valid} pairs -> {loss_sum, count}; run by ONE block (256 threads)
+__device__ __forceinline__ void finalize_loss(const float* __restrict__ row_lv, int n_rows, float* __restrict__ out2, NetState* state) {
+  __shared__ float sl[256], sv[256];
+  float l = 0.f, v = 0.f;
+  for (int r = threadIdx.x; r < n_rows; r += 256) { l += row_lv[2 * r]; v += row_lv[2 * r + 1]; }
+  sl[threadIdx.x] = l;
+  sv[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sv[threadIdx.x] += sv[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = sl[0];
+    out2[1] = sv[0];
+    if (state) { state->loss_sum = sl[0]; state->count = sv[0]; }
+  }
+}
+
 // dz[s][j, seg_e] = sum_{k in out_e(j)} g'[dst_k] / deg(dst_k);   dz[s][j, root] = g'[s][j]
 template <int GS, int NV>
 __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   constexpr int VEC = 4;
+  if ((int)blockIdx.x == a.total_blocks) {  // the extra block (only launched when fin_row_lv is set)
+    finalize_loss(a.fin_row_lv, a.fin_rows, a.fin_out2, a.fin_state);
+    return;
+  }
   int si = 0;
   while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
   const TAggSrc& S = a.s[si];
@@ -328,6 +407,108 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
         Acc<VEC> v;
         v.load(S.groot + (int64_t)row * S.ldgr + c);
         v.store(S.dz + (int64_t)row * S.lddz + S.roff + c);
+      }
+    }
+  }
+}
+
+// ----- transposed aggregation of layer l FUSED with its input-gradient GEMM ------------------------------------------
+// dH[l][s] = (dZ[l][s] * Wp[l][s]) . act'(H[l][s]) is row-local, so the block that has just gathered 16 rows of dZ keeps
+// them in LDS ([k][row] image, LD 17) and multiplies them on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): one
+// kernel and one hand-off of dZ through L2 less per layer.  dZ is still written to HBM (the weight-gradient GEMM reads it).
+// Wp [ncols][ldw] is read from L2: lane (n, kq) loads Wp[kb + kq][n0 + n] (16 lanes = one 64-byte segment).
+template <int GS>
+__global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
+  constexpr int TM = 16, LDH = 17, VEC = 4;
+  constexpr int RPP = 256 / GS;  // rows gathered per pass
+  constexpr int NP = TM / RPP;   // passes (GS = 16: 1, 32: 2, 64: 4)
+  extern __shared__ float Hs[];  // [ncols][LDH]
+  if ((int)blockIdx.x == a.total_blocks) {
+    finalize_loss(a.fin_row_lv, a.fin_rows, a.fin_out2, a.fin_state);
+    return;
+  }
+  int si = 0;
+  while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
+  const TAggSrc& S = a.s[si];
+  const int row0 = ((int)blockIdx.x - S.block_start) * TM;
+  const int c0 = (threadIdx.x % GS) * VEC;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int m = p * RPP + threadIdx.x / GS;
+    const int row = row0 + m;
+    const bool live = row < S.n_rows;
+    int rb[AGG_MAX_IN], re[AGG_MAX_IN];
+#pragma unroll
+    for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
+      rb[oi] = re[oi] = 0;
+      if (live && oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
+    }
+#pragma unroll
+    for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
+      if (oi >= S.n_out) break;
+      const TAggOut& O = S.out[oi];
+      Acc<VEC> acc[1];
+      acc[0].zero();
+      gather_sum_w<GS, 1, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, rb[oi], re[oi], c0, O.F);
+      if (c0 < O.F) {
+        if (live) acc[0].store(S.dz + (int64_t)row * S.lddz + O.coff + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Hs[(O.coff + c0 + i) * LDH + m] = acc[0].at(i);
+      }
+    }
+    if (S.groot && c0 < S.Froot) {
+      Acc<VEC> v;
+      v.zero();
+      if (live) {
+        v.load(S.groot + (int64_t)row * S.ldgr + c0);
+        v.store(S.dz + (int64_t)row * S.lddz + S.roff + c0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Hs[(S.roff + c0 + i) * LDH + m] = v.at(i);
+    }
+  }
+  if (S.xw == nullptr) return;  // block-uniform
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nn = lane & 15, kq = lane >> 4;
+  const int K = S.ncols;
+  const int n_ct = (S.xN + 15) >> 4;
+  for (int ct = w; ct < n_ct; ct += 4) {
+    const int col = ct * 16 + nn;
+    const float* wp = S.xw + min(col, S.xN - 1) + (int64_t)kq * S.xldw;  // clamped: padded columns are never stored
+    const float* hp = Hs + kq * LDH + nn;                                  // A operand: row m = lane & 15 of the tile
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // 8 k-steps per trip: the 8 (clamped) weight loads are in flight together, then the MFMA chain runs
+    for (int kb = 0; kb < K; kb += 32) {
+      float bv[8], av[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = min(kb + 4 * u, K - 4);
+        bv[u] = wp[(int64_t)k * S.xldw];
+        av[u] = hp[k * LDH];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (kb + 4 * u < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+    if (col < S.xN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + kq * 4 + r;
+        if (row >= S.n_rows) continue;
+        float v = acc[r];
+        if (S.xh) {
+          const float h = S.xh[(int64_t)row * S.xldh + col];
+          // dropped elements were stored as -0.0f by the forward: the keep bit is the sign of a zero
+          const bool keep = !S.xdrop_on || (__float_as_uint(h) != 0x80000000u);
+          float f = S.xscale;
+          if (!keep) f = 0.f;
+          else if (S.xact == HMP_ACT_RELU) f = h > 0.f ? S.xscale : 0.f;
+          else if (S.xact == HMP_ACT_ELU) f = h > 0.f ? S.xscale : (h + S.xscale);
+          v *= f;
+        }
+        S.xg[(int64_t)row * S.xldg + col] = v;
       }
     }
   }
@@ -410,7 +591,10 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
     for (int o = 0; o < a.s[i].n_out; ++o) Fmax = a.s[i].out[o].F > Fmax ? a.s[i].out[o].F : Fmax;
     if (a.s[i].groot) Fmax = a.s[i].Froot > Fmax ? a.s[i].Froot : Fmax;
   }
-  if (a.n == 0 || Fmax == 0) return HMP_OK;
+  if (a.n == 0 || Fmax == 0) {
+    if (!a.fin_row_lv) return HMP_OK;
+    Fmax = 4;  // nothing to gather, but the loss still has to be finalised
+  }
   int gs, nv;
   pick_shape(Fmax, vec, gs, nv);
   for (int i = 0; i < a.n; ++i) {
@@ -418,10 +602,43 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
     blocks += cdiv(a.s[i].n_rows, 256 / gs);
   }
   a.total_blocks = blocks;
-  if (blocks == 0) return HMP_OK;
-#define LAUNCH_BWD(GS_, NV_) hipLaunchKernelGGL((agg_bwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
+  if (blocks == 0 && !a.fin_row_lv) return HMP_OK;
+  const int grid = blocks + (a.fin_row_lv ? 1 : 0);
+#define LAUNCH_BWD(GS_, NV_) hipLaunchKernelGGL((agg_bwd_kernel<GS_, NV_>), dim3(grid), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_BWD)
 #undef LAUNCH_BWD
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st) {
+  int Fmax = 0, blocks = 0, kmax = 0;
+  for (int i = 0; i < a.n; ++i) {
+    for (int o = 0; o < a.s[i].n_out; ++o) Fmax = a.s[i].out[o].F > Fmax ? a.s[i].out[o].F : Fmax;
+    if (a.s[i].groot) Fmax = a.s[i].Froot > Fmax ? a.s[i].Froot : Fmax;
+    kmax = a.s[i].ncols > kmax ? a.s[i].ncols : kmax;
+    HMP_CHECK_ARG((a.s[i].ncols & 3) == 0, "agg_bwd_dx: ncols must be padded to 4");
+  }
+  if (a.n == 0 || Fmax == 0) {
+    if (!a.fin_row_lv) return HMP_OK;
+    Fmax = 4;
+  }
+  HMP_CHECK_ARG(Fmax <= 256 && kmax <= 896, "agg_bwd_dx: segment width %d / stacked width %d not supported", Fmax, kmax);
+  int gs = 16;
+  while (gs < 64 && gs * 4 < Fmax) gs <<= 1;
+  for (int i = 0; i < a.n; ++i) {
+    a.s[i].block_start = blocks;
+    blocks += cdiv(a.s[i].n_rows, 16);
+  }
+  a.total_blocks = blocks;
+  if (blocks == 0 && !a.fin_row_lv) return HMP_OK;
+  const int grid = blocks + (a.fin_row_lv ? 1 : 0);
+  const size_t smem = (size_t)kmax * 17 * sizeof(float);
+  switch (gs) {
+    case 16: hipLaunchKernelGGL((agg_bwd_dx_kernel<16>), dim3(grid), dim3(256), smem, st, a); break;
+    case 32: hipLaunchKernelGGL((agg_bwd_dx_kernel<32>), dim3(grid), dim3(256), smem, st, a); break;
+    default: hipLaunchKernelGGL((agg_bwd_dx_kernel<64>), dim3(grid), dim3(256), smem, st, a); break;
+  }
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

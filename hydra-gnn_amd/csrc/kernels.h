@@ -90,12 +90,21 @@ struct AggDst {
   const float* pw;  // null: this node type is not read by the next layer
   float* pz;
   int pldw, pldz, pncols, pK;
+  // fused masked cross entropy on the rows of this entry (last layer of the fused training step): gradient of the SUM loss
+  // to ce_grad, per-row {loss, valid} to ce_row_lv
+  const int64_t* ce_labels;  // null: off
+  int64_t ce_ignored;
+  int ce_classes, ce_ldg;
+  float* ce_grad;
+  float* ce_row_lv;
   AggIn in[AGG_MAX_IN];
 };
+struct NetState;
 struct AggArgs {
   int n;
   int total_blocks;
   int mean;  // divide every gather by max(deg,1)
+  NetState* state;  // status bits (fused cross entropy: label out of range)
   AggDst d[HMP_MAX_NODE_TYPES];
 };
 int agg_fwd_launch(AggArgs& a, hipStream_t st);
@@ -118,15 +127,28 @@ struct TAggSrc {
   int ldgr, roff, Froot;
   int n_out;
   int block_start;
+  // fused input gradient (agg_bwd_dx_launch): xg = (dz * xw) . act'(xh), xw = Wp[l][s] [ncols][xldw]
+  const float* xw;  // null: no input gradient for this node type
+  float* xg;
+  const float* xh;  // activations whose derivative masks xg (null: none)
+  int xldw, xN, xldg, xldh, xact, xdrop_on;
+  float xscale;
   TAggOut out[AGG_MAX_IN];
 };
 struct TAggArgs {
   int n;
   int total_blocks;
   int mean;
+  // one extra block sums the per-row {loss, valid} pairs of the loss in fixed order -> fin_out2 / fin_state (null: off)
+  const float* fin_row_lv;
+  int fin_rows;
+  float* fin_out2;
+  NetState* fin_state;
   TAggSrc s[HMP_MAX_NODE_TYPES];
 };
 int agg_bwd_launch(TAggArgs& a, hipStream_t st);
+// same + the row-local input-gradient GEMM per 16-row tile (requires every segment width <= 256, ncols <= 896)
+int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // parameter packing / gradient un-packing (tables live in device memory, built at bind time)
@@ -146,7 +168,6 @@ struct PackSeg {
   int64_t att;      // PACK_ATTDOT*: float offset of the attention vector [H*C]
   int64_t src[AGG_MAX_IN];  // float offsets into the flat parameter buffer (summed)
 };
-struct NetState;
 // block -> segment map of the table-driven kernels: segment i owns blocks [start[i], start[i+1]); passed by value so the
 // lookup is a scan of scalar (kernarg) loads instead of a dependent chain of global loads
 constexpr int SEG_MAX = 400;
@@ -262,10 +283,21 @@ int gat_fwd_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, 
 int gat_bwd1_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
 int gat_bwd2_launch(const GatLayerS* d_tab, const GatLayerS& h_tab, GatDyn& dyn, hipStream_t st);
 
+// Adam riding in the gradient un-pack (single-rank step of networks whose gradient terms read no parameters, i.e. SAGE):
+// the thread that produced gradient element i updates parameter i right away.  count = valid labels (device), step = t.
+struct AdamFuse {
+  int on;
+  float* p;
+  float* m;
+  float* v;
+  float lr, b1, b2, eps, wd;
+  const int* step_dev;
+  const float* count;
+};
 // row_lv != null: block (0,0) also sums the per-row {loss, valid} pairs (masked_ce_rows_launch) into out2 / state
 int grad_reduce_launch(const GradSeg* d_segs, const SegBlocks& sb, const GradReduceDyn& dyn, const float* d_slabs,
                        const float* d_params, float* d_grads, const float* row_lv, int n_lv_rows, float* out2, NetState* state,
-                       hipStream_t st);
+                       const AdamFuse& adam, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // loss / adam

@@ -121,6 +121,14 @@ struct hmp_net {
   bool use_branches = false;
   bool dw_branch = false;  // weight-gradient GEMMs per layer on a side stream instead of one merged launch
   int dw_mode = -1;        // HMP_DW_BRANCH override (0 / 1), -1 = automatic
+  int fuse_mode = -1;      // HMP_FUSE override (0 / 1), -1 = automatic: row-local GEMMs ride in the aggregation kernels
+  bool fuse_now = false;   // decision for the current batch
+  // fused training step: labels for the cross entropy riding in the last aggregation, Adam riding in the gradient un-pack
+  const int64_t* ce_labels = nullptr;
+  int64_t ce_ignored = 0;
+  bool ce_done = false;
+  AdamFuse adam_fuse = {};
+  bool adam_done = false;
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t evs[32];
   int n_evs = 0, ev_i = 0;
@@ -688,6 +696,16 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
   return plan_launch(pb, &n->d_state->status, st);
 }
 
+// Small (launch-latency-bound) batches: the row-local GEMM that follows an aggregation (next layer's projection in the
+// forward pass, the input gradient in the backward pass) runs inside the aggregation kernel on 16-row tiles.  Large
+// batches keep the stand-alone 64x64-tile GEMM (16-row tiles would re-read the weights from L2 once per 16 rows).
+inline bool fuse_small(const hmp_net* n, const hmp_batch* b) {
+  if (n->fuse_mode >= 0) return n->fuse_mode == 1;
+  int64_t total = 0;
+  for (int t = 0; t < n->T; ++t) total += b->n_nodes[t];
+  return total <= 16384;
+}
+
 inline bool is_input(const hmp_net* n, int l, int t) { return l == 0 || (l == 1 && n->pass0[t]); }
 const float* h_ptr(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.d_x[t] : n->H[l][t]; }
 int h_ld(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.ldx[t] : n->ld[l][t]; }
@@ -721,6 +739,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
   }
   bool z_done = false;
+  n->fuse_now = fuse_small(n, b);
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
@@ -759,9 +778,16 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
       AggArgs a;
       memset(&a, 0, sizeof(a));
       a.mean = 1;
+      a.state = n->d_state;
       for (int t = 0; t < n->T; ++t) {
         if (Y.roff[t] < 0 || b->n_nodes[t] == 0) continue;
         AggDst& D = a.d[a.n++];
+        if (l == n->L - 1 && t == S.readout_type && n->ce_labels && S.pool_edge_type < 0 && n->fuse_now && fpad(Ls.out_dim[t]) <= 256) {
+          // masked cross entropy in the epilogue of the last aggregation (one kernel less on the step's critical path)
+          D.ce_labels = n->ce_labels; D.ce_ignored = n->ce_ignored; D.ce_classes = n->out_dim;
+          D.ce_grad = n->d_gout; D.ce_ldg = n->out_ld; D.ce_row_lv = n->d_row_lv;
+          n->ce_done = true;
+        }
         D.n_rows = b->n_nodes[t];
         D.F = fpad(Ls.out_dim[t]);
         D.out = n->H[l + 1][t]; D.ldo = n->ld[l + 1][t];
@@ -781,7 +807,33 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           I.z = n->Z[l][C.src]; I.ldz = Y.ncols[C.src]; I.coff = Y.conv[c].coff;
         }
       }
-      HMP_TRY(agg_fwd_launch(a, st));
+      // fuse the projection of layer l+1 when every node type it reads is produced right here
+      bool fuse = n->fuse_now && l + 1 < n->L;
+      if (fuse) {
+        const LayerLayout& Yn = n->lay[l + 1];
+        for (int t = 0; t < n->T && fuse; ++t) {
+          if (Yn.ncols[t] == 0 || b->n_nodes[t] == 0) continue;
+          if (Y.roff[t] < 0 || is_input(n, l + 1, t)) fuse = false;                   // not produced by this launch
+          if ((n->dim[l + 1][t] & 15) != 0 || n->dim[l + 1][t] > 256) fuse = false;  // kernel limits
+        }
+        for (int i = 0; i < a.n && fuse; ++i)
+          if (a.d[i].F > 256) fuse = false;
+      }
+      if (fuse) {
+        const LayerLayout& Yn = n->lay[l + 1];
+        int ai = 0;
+        for (int t = 0; t < n->T; ++t) {
+          if (Y.roff[t] < 0 || b->n_nodes[t] == 0) continue;
+          AggDst& D = a.d[ai++];
+          if (Yn.ncols[t] == 0) continue;
+          D.pw = n->d_packed + Yn.wp_off[t]; D.pldw = Yn.ldw[t]; D.pncols = Yn.ncols[t]; D.pK = n->dim[l + 1][t];
+          D.pz = n->Z[l + 1][t]; D.pldz = Yn.ncols[t];
+        }
+        HMP_TRY(agg_proj_fwd_launch(a, st));
+        z_done = true;
+      } else {
+        HMP_TRY(agg_fwd_launch(a, st));
+      }
     }
   }
   if (S.pool_edge_type >= 0) {
@@ -825,6 +877,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   }
   std::vector<GemmProblem> wps;  // weight-gradient problems of all layers (merged mode)
   std::vector<int> wids;
+  bool fin_early = false;
   for (int l = n->L - 1; l >= 0; --l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
@@ -833,6 +886,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       ldg = n->ld[l + 1][t];
       return n->G[l + 1][t];
     };
+    bool dx_fused = false;
     if (Y.kind == HMP_CONV_GAT) {
       Scope sc(n, KC_GAT_BWD, st);
       GatDyn dyn = make_gat_dyn(n, b);
@@ -844,6 +898,11 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       TAggArgs a;
       memset(&a, 0, sizeof(a));
       a.mean = 1;
+      if (n->fin_loss) {  // first backward kernel of the step: one extra block finalises {loss_sum, count}
+        a.fin_row_lv = n->d_row_lv; a.fin_rows = b->n_out; a.fin_out2 = d_grads + n->spec.n_active_params; a.fin_state = n->d_state;
+        n->fin_loss = false;
+        fin_early = true;
+      }
       for (int s = 0; s < n->T; ++s) {
         if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
         TAggSrc& T = a.s[a.n++];
@@ -866,7 +925,34 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           O.ldg = ldg; O.coff = Y.conv[c].coff; O.F = fpad(C.f_out);
         }
       }
-      HMP_TRY(agg_bwd_launch(a, st));
+      // input gradient of layer l inside the same kernel (row-local GEMM on 16-row tiles) for small batches
+      dx_fused = n->fuse_now && l > 0;
+      int fmax = 0;
+      for (int i = 0; i < a.n && dx_fused; ++i) {
+        if (a.s[i].ncols > 896) dx_fused = false;
+        for (int o = 0; o < a.s[i].n_out; ++o) fmax = a.s[i].out[o].F > fmax ? a.s[i].out[o].F : fmax;
+        if (a.s[i].groot) fmax = a.s[i].Froot > fmax ? a.s[i].Froot : fmax;
+      }
+      if (fmax > 256) dx_fused = false;
+      if (dx_fused) {
+        const hmp_layer_spec& Lp = S.layers[l - 1];
+        int ai = 0;
+        for (int s = 0; s < n->T; ++s) {
+          if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
+          TAggSrc& T = a.s[ai++];
+          if (!n->G[l][s]) continue;  // passthrough input of layer 1: no gradient wanted
+          T.xw = n->d_packed + Y.wp_off[s]; T.xldw = Y.ldw[s]; T.xN = n->dim[l][s];
+          T.xg = n->G[l][s]; T.xldg = n->ld[l][s];
+          T.xdrop_on = (n->training && Lp.dropout > 0.f) ? 1 : 0;
+          T.xact = Lp.act;
+          T.xscale = T.xdrop_on ? 1.f / (1.f - Lp.dropout) : 1.f;
+          T.xh = (T.xact != HMP_ACT_NONE || T.xdrop_on) ? n->H[l][s] : nullptr;
+          T.xldh = n->ld[l][s];
+        }
+        HMP_TRY(agg_bwd_dx_launch(a, st));
+      } else {
+        HMP_TRY(agg_bwd_launch(a, st));
+      }
     }
     // dZ[l] is complete.  Weight-gradient GEMMs: either ALL layers in one grouped split-K launch after the loop
     // (default: one launch with ~1k workgroups instead of L launches, and no cross-queue fork per layer -- each fork
@@ -876,7 +962,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       wst = n->side[1];
       HMP_TRY(fork_to(n, st, wst));
     }
-    const bool need_dx = (l > 0) || (d_gx != nullptr);
+    const bool need_dx = !dx_fused && ((l > 0) || (d_gx != nullptr));
     if (need_dx) {  // input gradient, masked by the previous layer's activation/dropout derivative
       Scope sc(n, KC_GEMM_BWD, st);
       std::vector<GemmProblem> ps;
@@ -974,8 +1060,13 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   {
     Scope sc(n, KC_GRAD_REDUCE, st);
     const int64_t na = n->spec.n_active_params;
+    // Adam inside the un-pack: needs the valid-label count before the kernel starts (finalised by the first backward
+    // kernel) and gradient terms that read no parameters (no GAT layer)
+    AdamFuse af = n->adam_fuse;
+    af.on = (af.on && fin_early && !n->any_gat) ? 1 : 0;
+    n->adam_done = af.on != 0;
     HMP_TRY(grad_reduce_launch(n->d_grad_segs, n->grad_sb, n->dyn, n->d_slabs, d_params, d_grads,
-                               n->fin_loss ? n->d_row_lv : nullptr, b->n_out, d_grads + na, n->d_state, st));
+                               n->fin_loss ? n->d_row_lv : nullptr, b->n_out, d_grads + na, n->d_state, af, st));
     n->fin_loss = false;
   }
   return HMP_OK;
@@ -1004,6 +1095,8 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
     n->use_branches = ok && n->n_evs == 32;
     const char* db = getenv("HMP_DW_BRANCH");
     n->dw_mode = db ? (db[0] == '1' ? 1 : 0) : -1;  // -1: decide per batch (see backward_impl)
+    const char* fz = getenv("HMP_FUSE");
+    n->fuse_mode = fz ? (fz[0] == '1' ? 1 : 0) : -1;
   }
   if (r != HMP_OK) {
     hmp_net_destroy(n);
@@ -1072,16 +1165,35 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
   HMP_CHECK_ARG(batch->d_labels != nullptr, "hmp_net_step_fwd_bwd: labels required");
   hipStream_t st = (hipStream_t)stream;
   n->training = args->training; n->seed = args->seed; n->rng_step = 0; n->step_dev = true;
-  HMP_TRY(forward_impl(n, batch, d_params, st));
-  const int64_t na = n->spec.n_active_params;
-  {
+  n->ce_labels = batch->d_labels; n->ce_ignored = args->ignored_label; n->ce_done = false;
+  const int rf = forward_impl(n, batch, d_params, st);
+  n->ce_labels = nullptr;
+  HMP_TRY(rf);
+  if (!n->ce_done) {
     Scope sc(n, KC_LOSS, st);
     HMP_TRY(masked_ce_rows_launch(out_ptr(n), n->out_ld, batch->n_out, n->out_dim, batch->d_labels, args->ignored_label, n->d_gout,
                                   n->out_ld, n->d_row_lv, n->d_state, st));
-    n->fin_loss = true;  // {loss_sum, count} -> d_grads[na], d_grads[na + 1] in the gradient un-pack
-    (void)na;
   }
+  // {loss_sum, count} -> d_grads[na], d_grads[na + 1]: by the first transposed aggregation, else by the gradient un-pack
+  n->fin_loss = true;
   return backward_impl(n, n->d_gout, n->out_ld, d_grads, d_params, nullptr, st);
+}
+
+extern "C" int hmp_net_step_fused(hmp_net* n, const hmp_batch* batch, float* d_params, float* d_grads, float* d_m, float* d_v,
+                                  const hmp_train_args* args, void* stream) {
+  HMP_CHECK_ARG(n && batch && d_params && d_grads && d_m && d_v && args, "hmp_net_step_fused: null argument");
+  AdamFuse& af = n->adam_fuse;
+  af.on = n->fuse_mode == 0 ? 0 : 1;
+  af.p = d_params; af.m = d_m; af.v = d_v;
+  af.lr = args->lr; af.b1 = args->beta1; af.b2 = args->beta2; af.eps = args->eps; af.wd = args->weight_decay;
+  af.step_dev = &n->d_state->step;
+  af.count = d_grads + n->spec.n_active_params + 1;
+  n->adam_done = false;
+  const int r = hmp_net_step_fwd_bwd(n, batch, d_params, d_grads, args, stream);
+  af.on = 0;
+  HMP_TRY(r);
+  if (n->adam_done) return HMP_OK;
+  return hmp_net_step_adam(n, d_params, d_grads, d_m, d_v, args, stream);
 }
 
 extern "C" int hmp_net_step_adam(hmp_net* n, float* d_params, const float* d_grads, float* d_m, float* d_v,

@@ -200,9 +200,9 @@ int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_param
 // loss kernel in fixed order into out2 = {loss_sum, count} (the tail of the flat gradient buffer).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, const SegBlocks sb, const GradReduceDyn dyn,
-                                                          const float* __restrict__ slabs, const float* __restrict__ params,
+                                                          const float* __restrict__ slabs, const float* params,
                                                           float* __restrict__ grads, const float* __restrict__ row_lv, int n_lv_rows,
-                                                          float* __restrict__ out2, NetState* state) {
+                                                          float* __restrict__ out2, NetState* state, const AdamFuse adam) {
   int si = 0;
   while (si + 1 < sb.n && (int)blockIdx.x >= sb.start[si + 1]) ++si;
   const GradSeg& S = segs[si];
@@ -279,6 +279,24 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
       total += v * T.scale;
     }
     grads[S.dst + i] = total;
+    if (adam.on) {
+      // torch.optim.Adam with coupled L2 on this element (same arithmetic as adam_kernel); only taken when no gradient
+      // term of the network reads parameters (SAGE), so updating in place cannot race with another thread's reads
+      const int t = *adam.step_dev;
+      const float bc1 = 1.f - powf(adam.b1, (float)t);
+      const float bc2 = 1.f - powf(adam.b2, (float)t);
+      const float c = *adam.count;
+      const float gscale = 1.f / (c > 1.f ? c : 1.f);
+      const int64_t e = S.dst + i;
+      const float pi = adam.p[e];
+      const float gi = total * gscale + adam.wd * pi;
+      const float mi = adam.b1 * adam.m[e] + (1.f - adam.b1) * gi;
+      const float vi = adam.b2 * adam.v[e] + (1.f - adam.b2) * gi * gi;
+      adam.m[e] = mi;
+      adam.v[e] = vi;
+      const float denom = sqrtf(vi) / sqrtf(bc2) + adam.eps;
+      adam.p[e] = pi - (adam.lr / bc1) * (mi / denom);
+    }
     }
   }
   if (row_lv != nullptr && blockIdx.x == 0) {
@@ -302,10 +320,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
 
 int grad_reduce_launch(const GradSeg* d_segs, const SegBlocks& sb, const GradReduceDyn& dyn, const float* d_slabs,
                        const float* d_params, float* d_grads, const float* row_lv, int n_lv_rows, float* out2, NetState* state,
-                       hipStream_t st) {
+                       const AdamFuse& adam, hipStream_t st) {
   if (sb.n == 0 || sb.start[sb.n] == 0) return HMP_OK;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(sb.start[sb.n]), dim3(256), 0, st, d_segs, sb, dyn, d_slabs, d_params, d_grads, row_lv,
-                     n_lv_rows, out2, state);
+                     n_lv_rows, out2, state, adam);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

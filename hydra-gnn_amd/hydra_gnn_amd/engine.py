@@ -414,6 +414,12 @@ class TrainStep:
         _lib.check(net._lib.hmp_net_step_fwd_bwd(net._handle, C.byref(h.c), self.flat.data_ptr(), self.grads.data_ptr(),
                                                  C.byref(self.args), st))
 
+    def _phase_ab(self, h, st):
+        """single rank: both phases in one native call (Adam may ride in the gradient un-pack kernel)"""
+        net = self.net
+        _lib.check(net._lib.hmp_net_step_fused(net._handle, C.byref(h.c), self.flat.data_ptr(), self.grads.data_ptr(),
+                                               self.m.data_ptr(), self.v.data_ptr(), C.byref(self.args), st))
+
     def _phase_b(self, st):
         net = self.net
         _lib.check(net._lib.hmp_net_step_adam(net._handle, self.flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
@@ -429,9 +435,12 @@ class TrainStep:
             net._ensure_workspace(h, dev)
             if not self.use_graph:
                 st = _lib.stream_ptr()
-                self._phase_a(h, st)
-                self._all_reduce()
-                self._phase_b(st)
+                if self._world() == 1 and not self.force_collective:
+                    self._phase_ab(h, st)
+                else:
+                    self._phase_a(h, st)
+                    self._all_reduce()
+                    self._phase_b(st)
                 self._holder = h
                 return
             key = (tuple(h.n_nodes), tuple(h.n_edges), tuple(t.data_ptr() for t in h.keep), id(net._ws))
@@ -460,9 +469,10 @@ class TrainStep:
             single = self._world() == 1 and not self.force_collective  # no collective between the phases: ONE graph per step
             _lib.check(net._lib.hmp_graph_begin(st))
             try:
-                self._phase_a(h, st)
                 if single:
-                    self._phase_b(st)
+                    self._phase_ab(h, st)
+                else:
+                    self._phase_a(h, st)
             finally:
                 _lib.check(net._lib.hmp_graph_end(st, C.byref(ga)))
             if single:

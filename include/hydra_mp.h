@@ -246,6 +246,10 @@ int hmp_net_step_fwd_bwd(hmp_net* net, const hmp_batch* batch, const float* d_pa
                          const hmp_train_args* args, void* stream);
 int hmp_net_step_adam(hmp_net* net, float* d_params, const float* d_grads, float* d_m, float* d_v,
                       const hmp_train_args* args, void* stream);
+/* single-rank step: phase A + phase B in one call (no collective in between).  Lets the executor fold Adam into the
+ * gradient un-pack kernel where the network allows it (SAGE stacks); the result equals A followed by B. */
+int hmp_net_step_fused(hmp_net* net, const hmp_batch* batch, float* d_params, float* d_grads, float* d_m, float* d_v,
+                       const hmp_train_args* args, void* stream);
 /* host copy of {step counter, status bits}; synchronises the stream */
 int hmp_net_read_state(hmp_net* net, int32_t* step, int32_t* status, void* stream);
 

@@ -1,0 +1,178 @@
+"""Small-batch fusions (row-local GEMMs and the masked cross entropy riding in the aggregation kernels, Adam riding in the
+gradient un-pack) against the stand-alone kernels and against the oracle.
+
+HMP_FUSE=0 / 1 pins the executor to the stand-alone / fused launch sequence (read when the native net is created);
+unset = automatic (fused up to 16384 nodes per batch).  Both sequences must satisfy the oracle tolerance, and they must
+agree with each other far inside it (they differ only in fp32 summation order of the projections).
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hydra_gnn_amd import workloads  # noqa: E402
+from hydra_gnn_amd.models import HeterogeneousNetwork, HeterogeneousNeuralTreeNetwork  # noqa: E402
+from oracle import models as omodels  # noqa: E402
+
+ATOL, RTOL = 1e-5, 1e-5
+DEV = "cuda:0"
+HT_DIMS = {"object": 306, "room": 6, "object-room": 6, "room-room": 6, "object_virtual": 306, "room_virtual": 6}
+
+
+class fuse_env:
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        self.old = os.environ.get("HMP_FUSE")
+        if self.value is None:
+            os.environ.pop("HMP_FUSE", None)
+        else:
+            os.environ["HMP_FUSE"] = self.value
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("HMP_FUSE", None)
+        else:
+            os.environ["HMP_FUSE"] = self.old
+
+
+def build(kw, cls, ocls, sd=None, seed=0):
+    torch.manual_seed(seed)
+    ora = ocls(**kw)
+    if sd is not None:
+        ora.load_state_dict(sd)
+    net = cls(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    return ora, net.to(DEV)
+
+
+def run_fwd_bwd(net, batch, label_type, train=False):
+    net.train(train)
+    gb = batch.to(DEV)
+    pred = net(gb)
+    y = gb[label_type].y
+    loss = net.loss(pred, y, y != 25)
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+    return pred.detach().clone(), loss.detach().clone(), grads
+
+
+SAGE_KW = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, conv_block="GraphSAGE", hidden_dim=64, num_layers=3,
+               dropout=0.0)
+
+
+@pytest.mark.parametrize("hidden,layers,dropout", [(64, 3, 0.0), (128, 4, 0.0), (256, 3, 0.0), (64, 3, 0.25), (48, 3, 0.0), (40, 3, 0.0)])
+def test_fused_and_standalone_sequences_agree(hidden, layers, dropout):
+    """(48: K % 16 == 0 -> fused; 40: not a multiple of 16 -> the forward projection silently stays stand-alone)"""
+    kw = dict(SAGE_KW, hidden_dim=hidden, num_layers=layers, dropout=dropout)
+    batch = workloads.config2_batch(8)
+    res = {}
+    for mode in ("0", "1"):
+        with fuse_env(mode):
+            _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+            res[mode] = run_fwd_bwd(net, batch, "rooms", train=dropout > 0)
+    p0, l0, g0 = res["0"]
+    p1, l1, g1 = res["1"]
+    torch.testing.assert_close(p1, p0, atol=2e-6, rtol=2e-6)
+    torch.testing.assert_close(l1, l0, atol=2e-6, rtol=2e-6)
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None)
+        if g0[k] is not None:
+            torch.testing.assert_close(g1[k], g0[k], atol=2e-6, rtol=2e-5, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_both_sequences_match_the_oracle(mode):
+    batch = workloads.config2_batch(8)
+    with fuse_env(mode):
+        ora, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+        pred, loss, grads = run_fwd_bwd(net, batch, "rooms")
+    o64 = copy.deepcopy(ora).double()
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    pred_ref = o64(b64)
+    y = batch["rooms"].y
+    loss_ref = o64.loss(pred_ref, y, y != 25)
+    loss_ref.backward()
+    torch.testing.assert_close(pred.cpu().double(), pred_ref.detach(), atol=ATOL, rtol=RTOL)
+    torch.testing.assert_close(loss.cpu().double(), loss_ref.detach(), atol=ATOL, rtol=RTOL)
+    for name, p in o64.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(grads[name].cpu().double(), p.grad, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_step_equals_two_phase_step(use_graph):
+    """cross entropy in the last aggregation + Adam in the gradient un-pack == loss kernel + Adam kernel (5 steps, dropout on:
+    both draw the same Philox masks)"""
+    kw = dict(SAGE_KW, dropout=0.25)
+    batch = workloads.config2_batch(8).to(DEV)
+    y = batch["rooms"].y
+    out = {}
+    for mode in ("0", "1"):
+        with fuse_env(mode):
+            _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+            net.train()
+            step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=99, use_graph=use_graph)
+            losses = []
+            for _ in range(5):
+                step(batch, y)
+                losses.append(step.loss())
+            st, status = net.native().read_state()
+            assert st == 5 and status == 0
+            out[mode] = (losses, {k: p.detach().clone() for k, p in net.named_parameters()})
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-5, atol=1e-6)
+    for k, p0 in out["0"][1].items():
+        # Adam divides by |g|: where |g| ~ eps a 1e-7 difference in g moves the parameter by a fraction of lr (the bound)
+        d = (out["1"][1][k] - p0).abs()
+        assert float(d.max()) <= 5 * 0.002 * 2.1, k
+        assert float((d > 2e-5).double().mean()) < 0.01, k
+
+
+def test_fused_cross_entropy_edge_cases():
+    """all labels ignored in one batch, an out-of-range label flagged in the status word (not a crash)"""
+    with fuse_env("1"):
+        _, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+        batch = workloads.config2_batch(4).to(DEV)
+        step = net.train_step(lr=0.002, weight_decay=0.0, ignored_label=25, use_graph=False)
+        before = {k: p.detach().clone() for k, p in net.named_parameters()}
+        y = torch.full_like(batch["rooms"].y, 25)
+        step(batch, y)
+        assert step.loss() == 0.0
+        for k, p in net.named_parameters():  # zero gradient, no weight decay: Adam leaves the weights alone
+            assert torch.equal(p.detach(), before[k]), k
+        y2 = batch["rooms"].y.clone()
+        y2[0] = 99
+        step(batch, y2)
+        _, status = net.native().read_state()
+        assert status & 2
+
+
+def test_htree_sequences_agree_and_pool_path_finalises_loss():
+    kw = dict(input_dim_dict=HT_DIMS, output_dim=26, conv_block="GraphSAGE", hidden_dim=128, num_layers=4,
+              disable_initialization=True, dropout=0.0)
+    batch = workloads.htree_batch(4, seed=5)
+    res, steps = {}, {}
+    for mode in ("0", "1"):
+        with fuse_env(mode):
+            _, net = build(kw, HeterogeneousNeuralTreeNetwork, omodels.HeterogeneousNeuralTreeNetwork)
+            res[mode] = run_fwd_bwd(net, batch, "room_virtual")
+            gb = batch.to(DEV)
+            step = net.train_step(lr=0.001, weight_decay=0.001, ignored_label=25, use_graph=False)
+            ls = []
+            for _ in range(3):
+                step(gb, gb["room_virtual"].y)
+                ls.append(step.loss())
+            steps[mode] = ls
+    torch.testing.assert_close(res["1"][0], res["0"][0], atol=2e-6, rtol=2e-6)
+    for k, g in res["0"][2].items():
+        if g is not None:
+            torch.testing.assert_close(res["1"][2][k], g, atol=2e-6, rtol=2e-5, msg=lambda m: f"{k}: {m}")
+    np.testing.assert_allclose(steps["1"], steps["0"], rtol=1e-5, atol=1e-6)
+    assert steps["1"][-1] < steps["1"][0]
