@@ -119,6 +119,7 @@ struct hmp_net {
 
   // parallel branches (side streams; under capture they become branches of the hipGraph)
   bool use_branches = false;
+  int branch_mask = 0;     // HMP_BRANCH bits: 1 = pack + layer-0 projection next to the plan, 2 = weight gradients next to the backward chain
   bool dw_branch = false;  // weight-gradient GEMMs per layer on a side stream instead of one merged launch
   int dw_mode = -1;        // HMP_DW_BRANCH override (0 / 1), -1 = automatic
   int fuse_mode = -1;      // HMP_FUSE override (0 / 1), -1 = automatic: row-local GEMMs ride in the aggregation kernels
@@ -732,7 +733,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   // (4-5 dependent launches of the) plan build and join before the first aggregation.  Under capture this becomes
   // two parallel branches of the hipGraph.
   hipStream_t main_st = st;
-  hipStream_t side = n->use_branches ? n->side[0] : main_st;
+  hipStream_t side = (n->use_branches && (n->branch_mask & 1)) ? n->side[0] : main_st;
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   {
     Scope sc(n, KC_PACK, side);
@@ -873,7 +874,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     // (+4 % at 6k nodes, +10 % at 12k)
     int total_nodes = 0;
     for (int t = 0; t < n->T; ++t) total_nodes += b->n_nodes[t];
-    n->dw_branch = n->use_branches && (n->dw_mode >= 0 ? n->dw_mode == 1 : total_nodes > 4096);
+    n->dw_branch = n->use_branches && (n->branch_mask & 2) && (n->dw_mode >= 0 ? n->dw_mode == 1 : total_nodes > 4096);
   }
   std::vector<GemmProblem> wps;  // weight-gradient problems of all layers (merged mode)
   std::vector<int> wids;
@@ -1085,8 +1086,12 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
   int r = build_layout(n);
   if (r == HMP_OK) r = build_tables(n);
   if (r == HMP_OK) {
-    const char* nb = getenv("HMP_NO_BRANCH");
-    bool ok = !(nb && nb[0] == '1');
+    // side-stream branches (pack + layer-0 projection next to the plan, weight gradients next to the backward chain) only
+    // on request: measured on MI355X, every fork/join costs ~10 us of dependency latency, more than the overlap buys once
+    // the plan is a single launch
+    const char* nb = getenv("HMP_BRANCH");
+    n->branch_mask = nb ? atoi(nb) : 0;
+    bool ok = n->branch_mask != 0;
     for (int i = 0; i < 2 && ok; ++i) ok = hipStreamCreateWithFlags(&n->side[i], hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 32 && ok; ++i) {
       ok = hipEventCreateWithFlags(&n->evs[i], hipEventDisableTiming) == hipSuccess;

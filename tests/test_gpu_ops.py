@@ -52,7 +52,8 @@ def rand_edges(rng, E, n_src, n_dst):
     return torch.from_numpy(np.stack([rng.integers(0, max(n_src, 1), E), rng.integers(0, max(n_dst, 1), E)]).astype(np.int64))
 
 
-@pytest.mark.parametrize("E,n_src,n_dst", [(0, 3, 4), (1, 1, 1), (17, 5, 3), (482, 62, 62), (20000, 700, 90), (5000, 1, 4000), (3000, 2000, 1)])
+@pytest.mark.parametrize("E,n_src,n_dst", [(0, 3, 4), (1, 1, 1), (17, 5, 3), (482, 62, 62), (20000, 700, 90), (5000, 1, 4000), (3000, 2000, 1),
+                                          (60000, 2500, 3100), (100000, 3000, 2500)])
 def test_plan_bit_exact(E, n_src, n_dst):
     rng = np.random.default_rng(E + n_src)
     ei = rand_edges(rng, E, n_src, n_dst)
@@ -75,6 +76,20 @@ def test_plan_bit_exact(E, n_src, n_dst):
         pos_of = torch.empty(E, dtype=torch.int64)
         pos_of[order] = torch.arange(E)
         assert torch.equal(p["t_pos"].cpu().long()[:E], pos_of[t_order])
+
+
+def test_plan_multi_launch_and_single_launch_builds_agree(monkeypatch):
+    """HMP_PLAN_SMALL pins the build: 0 = histogram/scan/fill/rank launches with global counters, 1 = one launch (LDS)"""
+    rng = np.random.default_rng(77)
+    for E, n_src, n_dst in [(482, 62, 62), (20000, 700, 90), (30000, 2300, 2300)]:
+        ei = rand_edges(rng, E, n_src, n_dst).to(dev())
+        monkeypatch.setenv("HMP_PLAN_SMALL", "0")
+        a = build_plan(ei, n_src, n_dst)
+        monkeypatch.setenv("HMP_PLAN_SMALL", "1")
+        b = build_plan(ei, n_src, n_dst)
+        monkeypatch.delenv("HMP_PLAN_SMALL")
+        for k in ("rowptr", "col", "eid", "t_rowptr", "t_col", "t_pos"):
+            assert torch.equal(a[k], b[k]), k
 
 
 def test_plan_flags_out_of_range_edges():
