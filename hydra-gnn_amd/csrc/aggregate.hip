@@ -13,6 +13,8 @@
 
 namespace hmp {
 
+KT_DEFINE(agg)
+
 // ----- row access helpers -----------------------------------------------------------------------
 // VEC = 4: 16-byte accesses (pointer and ld 16-byte aligned); VEC = 1: scalar fall-back for arbitrary ld.
 template <int VEC>
@@ -182,6 +184,51 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
     rb[ii] = re[ii] = 0;
     if (ii < D.n_in) { rb[ii] = D.in[ii].rowptr[row]; re[ii] = D.in[ii].rowptr[row + 1]; }
   }
+  if constexpr (NV == 1) {
+    // Incoming edge types in PAIRS: the neighbour ids of both types travel together, then the 16 neighbour rows -- three
+    // dependent round trips (extents, ids, rows) for two edge types instead of five.  A missing partner aliases the
+    // first type with an empty extent (loads hit the same lines, adds are masked).  Sums keep the edge order per type
+    // and the type order of the sequential code.
+    constexpr int UB = 8;
+#pragma unroll
+    for (int ii = 0; ii < AGG_MAX_IN; ii += 2) {
+      if (ii >= D.n_in) break;
+      const bool has2 = ii + 1 < D.n_in;
+      const AggIn& I0 = D.in[ii];
+      const AggIn& I1 = D.in[has2 ? ii + 1 : ii];
+      const int b0 = rb[ii], e0 = re[ii];
+      const int b1 = has2 ? rb[ii + 1] : b0, e1 = has2 ? re[ii + 1] : b0;
+      int j0[UB], j1[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        j0[u] = I0.col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
+        j1[u] = I1.col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+      }
+      Acc<VEC> v0[UB], v1[UB];
+      const bool cin = c0 < D.F;
+      const int cc = cin ? c0 : 0;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        v0[u].load(I0.z + I0.coff + (int64_t)j0[u] * I0.ldz + cc);
+        v1[u].load(I1.z + I1.coff + (int64_t)j1[u] * I1.ldz + cc);
+      }
+      Acc<VEC> a0[1], a1[1];
+      a0[0].zero();
+      a1[0].zero();
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (b0 + u < e0) a0[0].add(v0[u]);
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (b1 + u < e1) a1[0].add(v1[u]);
+      if (e0 - b0 > UB) gather_sum<GS, 1, VEC>(a0, I0.z + I0.coff, I0.ldz, I0.col, b0 + UB, e0, c0, D.F);
+      if (e1 - b1 > UB) gather_sum<GS, 1, VEC>(a1, I1.z + I1.coff, I1.ldz, I1.col, b1 + UB, e1, c0, D.F);
+      if (cin) {
+        if (e0 > b0) tot[0].add_div(a0[0], mean ? (float)(e0 - b0) : 1.f);
+        if (e1 > b1) tot[0].add_div(a1[0], mean ? (float)(e1 - b1) : 1.f);
+      }
+    }
+  } else {
 #pragma unroll
   for (int ii = 0; ii < AGG_MAX_IN; ++ii) {
     if (ii >= D.n_in) break;
@@ -195,6 +242,7 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
     const float d = mean ? (float)(e - b) : 1.f;
 #pragma unroll
     for (int q = 0; q < NV; ++q) tot[q].add_div(acc[q], d);
+  }
   }
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
@@ -298,6 +346,7 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
   const AggDst& D = a.d[ti];
   const int row0 = ((int)blockIdx.x - D.block_start) * TM;
   const int c0 = (threadIdx.x % GS) * 4;
+  KT(0);
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int m = p * RPP + threadIdx.x / GS;
@@ -312,6 +361,7 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
   }
   if (D.pw == nullptr) return;  // block-uniform: this node type is not read by the next layer
   __syncthreads();
+  KT(1);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
   const int n_ct = (D.pncols + 15) >> 4;
@@ -343,6 +393,7 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
       }
     }
   }
+  KT(2);
 }
 
 // fixed-order sum of the per-row {loss, valid} pairs -> {loss_sum, count}; run by ONE block (256 threads)
@@ -385,6 +436,57 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
     rb[oi] = re[oi] = 0;
     if (oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
   }
+  if constexpr (NV == 1) {
+    // outgoing edge types in PAIRS (see agg_row): ids of both, then degrees + gradient rows of both
+    constexpr int UB = 8;
+#pragma unroll
+    for (int oi = 0; oi < AGG_MAX_IN; oi += 2) {
+      if (oi >= S.n_out) break;
+      const bool has2 = oi + 1 < S.n_out;
+      const TAggOut& O0 = S.out[oi];
+      const TAggOut& O1 = S.out[has2 ? oi + 1 : oi];
+      const int b0 = rb[oi], e0 = re[oi];
+      const int b1 = has2 ? rb[oi + 1] : b0, e1 = has2 ? re[oi + 1] : b0;
+      int i0[UB], i1[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        i0[u] = O0.t_col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
+        i1[u] = O1.t_col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+      }
+      float d0[UB], d1[UB];
+      Acc<VEC> v0[UB], v1[UB];
+      const int cc0 = c0 < O0.F ? c0 : 0, cc1 = c0 < O1.F ? c0 : 0;
+      const bool dg = a.mean && O0.degf && O1.degf;  // block-uniform
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        d0[u] = dg ? O0.degf[i0[u]] : 1.f;
+        d1[u] = dg ? O1.degf[i1[u]] : 1.f;
+        v0[u].load(O0.g + (int64_t)i0[u] * O0.ldg + cc0);
+        v1[u].load(O1.g + (int64_t)i1[u] * O1.ldg + cc1);
+      }
+      if (a.mean && !dg) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int g0 = O0.rowptr[i0[u] + 1] - O0.rowptr[i0[u]], g1 = O1.rowptr[i1[u] + 1] - O1.rowptr[i1[u]];
+          d0[u] = (float)(g0 > 1 ? g0 : 1);
+          d1[u] = (float)(g1 > 1 ? g1 : 1);
+        }
+      }
+      Acc<VEC> a0[1], a1[1];
+      a0[0].zero();
+      a1[0].zero();
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (b0 + u < e0) a0[0].add_div(v0[u], d0[u]);
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (b1 + u < e1) a1[0].add_div(v1[u], d1[u]);
+      if (e0 - b0 > UB) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + UB, e0, c0, O0.F);
+      if (e1 - b1 > UB) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + UB, e1, c0, O1.F);
+      if (c0 < O0.F) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
+      if (has2 && c0 < O1.F) a1[0].store(S.dz + (int64_t)row * S.lddz + O1.coff + c0);
+    }
+  } else {
 #pragma unroll
   for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
     if (oi >= S.n_out) break;
@@ -398,6 +500,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       const int c = c0 + q * GS * VEC;
       if (c < O.F) acc[q].store(S.dz + (int64_t)row * S.lddz + O.coff + c);
     }
+  }
   }
   if (S.groot) {
 #pragma unroll
@@ -432,6 +535,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   const TAggSrc& S = a.s[si];
   const int row0 = ((int)blockIdx.x - S.block_start) * TM;
   const int c0 = (threadIdx.x % GS) * VEC;
+  KT(8);
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int m = p * RPP + threadIdx.x / GS;
@@ -443,17 +547,61 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
       rb[oi] = re[oi] = 0;
       if (live && oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
     }
+    // outgoing edge types in PAIRS (see agg_row): ids of both, then degrees + gradient rows of both
+    constexpr int UB = 8;
 #pragma unroll
-    for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
+    for (int oi = 0; oi < AGG_MAX_IN; oi += 2) {
       if (oi >= S.n_out) break;
-      const TAggOut& O = S.out[oi];
-      Acc<VEC> acc[1];
-      acc[0].zero();
-      gather_sum_w<GS, 1, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, rb[oi], re[oi], c0, O.F);
-      if (c0 < O.F) {
-        if (live) acc[0].store(S.dz + (int64_t)row * S.lddz + O.coff + c0);
+      const bool has2 = oi + 1 < S.n_out;
+      const TAggOut& O0 = S.out[oi];
+      const TAggOut& O1 = S.out[has2 ? oi + 1 : oi];
+      const int b0 = rb[oi], e0 = re[oi];
+      const int b1 = has2 ? rb[oi + 1] : b0, e1 = has2 ? re[oi + 1] : b0;
+      int i0[UB], i1[UB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Hs[(O.coff + c0 + i) * LDH + m] = acc[0].at(i);
+      for (int u = 0; u < UB; ++u) {
+        i0[u] = O0.t_col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
+        i1[u] = O1.t_col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+      }
+      float d0[UB], d1[UB];
+      Acc<VEC> v0[UB], v1[UB];
+      const int cc0 = c0 < O0.F ? c0 : 0, cc1 = c0 < O1.F ? c0 : 0;
+      const bool dg = a.mean && O0.degf && O1.degf;  // block-uniform
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        d0[u] = dg ? O0.degf[i0[u]] : 1.f;
+        d1[u] = dg ? O1.degf[i1[u]] : 1.f;
+        v0[u].load(O0.g + (int64_t)i0[u] * O0.ldg + cc0);
+        v1[u].load(O1.g + (int64_t)i1[u] * O1.ldg + cc1);
+      }
+      if (a.mean && !dg) {  // unit-test path without the plan's degree table
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int g0 = O0.rowptr[i0[u] + 1] - O0.rowptr[i0[u]], g1 = O1.rowptr[i1[u] + 1] - O1.rowptr[i1[u]];
+          d0[u] = (float)(g0 > 1 ? g0 : 1);
+          d1[u] = (float)(g1 > 1 ? g1 : 1);
+        }
+      }
+      Acc<VEC> a0[1], a1[1];
+      a0[0].zero();
+      a1[0].zero();
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (b0 + u < e0) a0[0].add_div(v0[u], d0[u]);
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (b1 + u < e1) a1[0].add_div(v1[u], d1[u]);
+      if (e0 - b0 > UB) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + UB, e0, c0, O0.F);
+      if (e1 - b1 > UB) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + UB, e1, c0, O1.F);
+      if (c0 < O0.F) {
+        if (live) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Hs[(O0.coff + c0 + i) * LDH + m] = a0[0].at(i);
+      }
+      if (has2 && c0 < O1.F) {
+        if (live) a1[0].store(S.dz + (int64_t)row * S.lddz + O1.coff + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Hs[(O1.coff + c0 + i) * LDH + m] = a1[0].at(i);
       }
     }
     if (S.groot && c0 < S.Froot) {
@@ -469,6 +617,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   }
   if (S.xw == nullptr) return;  // block-uniform
   __syncthreads();
+  KT(9);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nn = lane & 15, kq = lane >> 4;
   const int K = S.ncols;
@@ -478,18 +627,16 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     const float* wp = S.xw + min(col, S.xN - 1) + (int64_t)kq * S.xldw;  // clamped: padded columns are never stored
     const float* hp = Hs + kq * LDH + nn;                                  // A operand: row m = lane & 15 of the tile
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // 8 k-steps per trip: the 8 (clamped) weight loads are in flight together, then the MFMA chain runs
-    for (int kb = 0; kb < K; kb += 32) {
-      float bv[8], av[8];
+    // 48 k-steps (192 stacked columns) per trip: the (clamped) weight loads are all in flight together, then the MFMA
+    // chain runs -- one L2 round trip for the typical stacked width instead of one per 8 steps
+    constexpr int WB = 48;
+    for (int kb = 0; kb < K; kb += 4 * WB) {
+      float bv[WB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = min(kb + 4 * u, K - 4);
-        bv[u] = wp[(int64_t)k * S.xldw];
-        av[u] = hp[k * LDH];
-      }
+      for (int u = 0; u < WB; ++u) bv[u] = wp[(int64_t)min(kb + 4 * u, K - 4) * S.xldw];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (kb + 4 * u < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      for (int u = 0; u < WB; ++u)
+        if (kb + 4 * u < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[(kb + 4 * u) * LDH], bv[u], acc, 0, 0, 0);
     }
     // D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
     if (col < S.xN) {
@@ -512,6 +659,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
       }
     }
   }
+  KT(10);
 }
 
 // ----- dispatch ---------------------------------------------------------------------------------------

@@ -47,6 +47,26 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int align4(int x) { return (x + 3) & ~3; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- in-kernel phase timestamps (profiling build only: make KTIME=1) -------------------------------------------
+// KT(i) stores the 100 MHz wall clock of thread 0 of block 0 into slot i of the translation unit's buffer;
+// hmp_debug_ktime_<tag>(out[64]) copies the buffer to the host.  Compiled out of the product library.
+#ifdef HMP_KTIME
+#define KT_DEFINE(tag)                                                                                   \
+  static __device__ unsigned long long kt_buf[64];                                                       \
+  extern "C" int hmp_debug_ktime_##tag(unsigned long long* out) {                                        \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_buf), sizeof(kt_buf)) == hipSuccess ? 0 : 1;           \
+  }
+#define KT(i)                                                                      \
+  do {                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = wall_clock64();           \
+  } while (0)
+#else
+#define KT_DEFINE(tag)
+#define KT(i) \
+  do {        \
+  } while (0)
+#endif
+
 // ---- Philox4x32-10 (counter based; the same element always draws the same number, so the
 //      backward pass regenerates the forward's keep-mask instead of storing it) ------------------
 struct Philox4 {

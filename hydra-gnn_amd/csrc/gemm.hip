@@ -21,6 +21,8 @@
 
 namespace hmp {
 
+KT_DEFINE(gemm)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A (ROWS x BK) tile in registers; logical element (r, k).
@@ -245,14 +247,18 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
 
   TileRegs<BM, BK> ra;
   TileRegs<BN, BK> rb;
+  KT(0);
   // for A the "row" dimension is M; for B it is N (n_real real columns, optional virtual ones column)
   tile_load<BM, BK>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kbeg, kend, a_vec);
   tile_load<BN, BK>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kbeg, kend, b_vec);
 
+  int kti = 0;
+  (void)kti;
   for (int kt = kbeg; kt < kend; kt += BK) {
     tile_store<BM, BK>(ra, As, a_kcontig);
     tile_store<BN, BK>(rb, Bs, b_kcontig);
     __syncthreads();
+    KT(1 + (kti++));
     if (kt + BK < kend) {
       tile_load<BM, BK>(ra, P.A, P.lda, a_kcontig, m0, P.M, P.M, 0, kt + BK, kend, a_vec);
       tile_load<BN, BK>(rb, P.B, P.ldb, b_kcontig, n0, P.n_real, P.n_real, P.aug_ones, kt + BK, kend, b_vec);
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
     __syncthreads();
   }
 
+  KT(8);
   if (KW > 1) {  // fixed-order cross-wave reduction through LDS
     float* red = smem;
     if (kw > 0) {
@@ -319,6 +326,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
     }
     C[(int64_t)row * P.ldc + col] = v;
   }
+  KT(9);
 }
 
 template <int WM, int WN, int BK>

@@ -39,6 +39,68 @@ struct GemmBatch {
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
+// front kernel of the small-batch step (front.hip): layer-0 projection tiles + plan parts + pack blocks in one launch
+// ---------------------------------------------------------------------------------------------
+constexpr int FR_MAX_PROB = 4;
+constexpr int FR_MAX_SEG = 6;
+constexpr int FR_MAX_SRC = 6;  // == AGG_MAX_IN
+struct FrontSeg {    // rows [col0, col0 + rows) of the stacked B operand = sum of nsrc parameter blocks [rows][ld]
+  int col0, rows, nsrc, ld;
+  uint32_t off[FR_MAX_SRC];  // float offsets into the flat parameter buffer
+};
+struct FrontProb {   // C[M, N] = A[M, K] * B^T
+  const float* A;
+  float* C;
+  int lda, ldc, M, N, K;
+  int n_seg, max_nsrc, vec;
+  int blk_start, tiles_m, tiles_n;
+  FrontSeg seg[FR_MAX_SEG];
+};
+struct FrontJob {    // one edge type of the plan; arrays as 4-byte-word offsets from the workspace base
+  const int64_t* ei;
+  int E, n_src, n_dst;
+  uint32_t rowptr, col, eid, t_rowptr, t_col, t_eid, tmp_in, tmp_out, pos_of_eid, degf;
+};
+struct PackSeg;
+struct NetState;
+struct FrontArgs {
+  // roles by block index: [0, gemm_blocks) projection tiles, then plan parts, then pack blocks
+  int gemm_blocks, plan_blocks, pack_blocks;
+  int n_prob, n_jobs, need_tpos, plan_rc;
+  const float* params;
+  char* ws;
+  int* status;
+  const PackSeg* segs;
+  const int2* pack_map;  // per pack block: {segment, first item}; 16 items (packed row, 64-column chunk) per block
+  float* packed;
+  NetState* state;       // non-null: the pack role's first block bumps the step counter
+  int part_start[2 * HMP_MAX_EDGE_TYPES + 1];
+  int rows_per_part[2 * HMP_MAX_EDGE_TYPES];
+  FrontJob job[HMP_MAX_EDGE_TYPES];
+  FrontProb prob[FR_MAX_PROB];
+};
+int front_launch(FrontArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// register-direct TN GEMM for small batches (gemm_direct.hip)
+// ---------------------------------------------------------------------------------------------
+struct TnProblem {   // slab z of C[M, N] = sum_{k in chunk z} A[k, m] * [B | 1][k, n]
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t slab_stride;
+  int M, N, K, lda, ldb, ldc;
+  int n_real, aug_ones;
+  int ksplit, kchunk, tile_start, tiles_m, tiles_n;
+};
+struct TnBatch {
+  int n, total_tiles;
+  TnProblem p[GEMM_MAX_PROB];
+};
+// *ok = 0 (nothing launched) when a problem would need more than max_slabs slabs
+int gemm_tn_direct_launch(TnBatch& tb, int max_slabs, int* ok, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------
 struct PlanJob {
@@ -99,7 +161,6 @@ struct AggDst {
   float* ce_row_lv;
   AggIn in[AGG_MAX_IN];
 };
-struct NetState;
 struct AggArgs {
   int n;
   int total_blocks;

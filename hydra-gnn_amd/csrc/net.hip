@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "kernels.h"
+#include "plan_small.h"
 
 using namespace hmp;
 
@@ -87,6 +87,10 @@ struct hmp_net {
   int max_pack_rows = 0;
   int64_t max_grad_elems = 0;
   SegBlocks pack_sb, grad_sb;
+  int2* d_pack_map = nullptr;  // front kernel: pack block (16 items) -> {segment, first item}
+  int n_pack_blocks16 = 0;
+  char* ws_base = nullptr;
+  size_t ws_bytes = 0;
   float* degf[HMP_MAX_EDGE_TYPES];  // max(in-degree,1) per destination node, by-product of the plan
   float* d_row_lv = nullptr;        // per output row {loss, valid} of the fused step's loss kernel
   bool fin_loss = false;            // the next gradient un-pack also finalises {loss_sum, count}
@@ -437,6 +441,18 @@ int build_tables(hmp_net* n) {
   n->pack_sb.start[0] = 0;
   for (size_t i = 0; i < ps.size(); ++i)  // one wave per (row, 64-column chunk), 4 waves per block
     n->pack_sb.start[i + 1] = n->pack_sb.start[i] + cdiv((int64_t)ps[i].rows_pad * cdiv(ps[i].ld_dst, 64), 4);
+  {
+    std::vector<int2> pm;
+    for (size_t i = 0; i < ps.size(); ++i) {
+      const int items = ps[i].rows_pad * cdiv(ps[i].ld_dst, 64);
+      for (int it = 0; it < items; it += 16) pm.push_back(make_int2((int)i, it));
+    }
+    n->n_pack_blocks16 = (int)pm.size();
+    if (!pm.empty()) {
+      HMP_HIP(hipMalloc(&n->d_pack_map, pm.size() * sizeof(int2)));
+      HMP_HIP(hipMemcpy(n->d_pack_map, pm.data(), pm.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
+  }
   n->grad_sb.n = (int)gs.size();
   n->grad_sb.start[0] = 0;
   for (size_t i = 0; i < gs.size(); ++i) {
@@ -624,7 +640,7 @@ int fork_to(hmp_net* n, hipStream_t from, hipStream_t to) {
   return HMP_OK;
 }
 
-enum { KC_PLAN = 0, KC_PACK, KC_GEMM_FWD, KC_AGG_FWD, KC_LOSS, KC_AGG_BWD, KC_GEMM_BWD, KC_GRAD_REDUCE, KC_ADAM, KC_GAT_FWD, KC_GAT_BWD, KC_POOL };
+enum { KC_PLAN = 0, KC_PACK, KC_GEMM_FWD, KC_AGG_FWD, KC_LOSS, KC_AGG_BWD, KC_GEMM_BWD, KC_GRAD_REDUCE, KC_ADAM, KC_GAT_FWD, KC_GAT_BWD, KC_POOL, KC_FRONT };
 
 DropCfg make_drop(const hmp_net* n, float p, uint32_t stream) {
   DropCfg d;
@@ -674,9 +690,7 @@ int check_batch(const hmp_net* n, const hmp_batch* b) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------
-int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
-  Scope sc(n, KC_PLAN, st);
-  PlanBatch pb;
+void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb) {
   memset(&pb, 0, sizeof(pb));
   pb.n = n->ET;
   pb.need_tpos = n->any_gat ? 1 : 0;
@@ -694,6 +708,12 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
     J.t_rowptr = P.d_t_rowptr; J.t_col = P.d_t_col; J.t_pos = P.d_t_pos;
     plan_carve(J, n->plan_scratch[e]);
   }
+}
+
+int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
+  Scope sc(n, KC_PLAN, st);
+  PlanBatch pb;
+  fill_plan_batch(n, b, pb);
   return plan_launch(pb, &n->d_state->status, st);
 }
 
@@ -725,6 +745,82 @@ int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std
   return HMP_OK;
 }
 
+void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb);
+
+// Front kernel arguments (layer-0 projection + plan + pack in one launch); false when the batch / network does not fit its
+// limits (the caller then launches pack, projection and plan separately).
+bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArgs& fa) {
+  const char* fv = getenv("HMP_FRONT");  // 0: separate pack / projection / plan launches (tests)
+  if ((fv && fv[0] == '0') || n->any_gat || !n->d_pack_map) return false;
+  const hmp_net_spec& S = n->spec;
+  const hmp_layer_spec& Ls = S.layers[0];
+  const LayerLayout& Y = n->lay[0];
+  if (Y.kind != HMP_CONV_SAGE) return false;
+  memset(&fa, 0, sizeof(fa));
+  // ---- projection problems
+  for (int s = 0; s < n->T; ++s) {
+    if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
+    if (fa.n_prob == FR_MAX_PROB) return false;
+    FrontProb& P = fa.prob[fa.n_prob++];
+    P.A = b->d_x[s]; P.lda = b->ldx[s];
+    P.C = n->Z[0][s]; P.ldc = Y.ncols[s];
+    P.M = b->n_nodes[s]; P.N = Y.ncols[s]; P.K = n->dim[0][s];
+    if (P.K < 4 || P.K > 384 || (P.K & 1) || (P.lda & 1) || (reinterpret_cast<uintptr_t>(P.A) & 7)) return false;
+    for (int i = 0; i < Y.n_live; ++i) {
+      const int c = Y.live[i];
+      const hmp_conv_spec& C = Ls.convs[c];
+      if (C.src != s) continue;
+      if (P.n_seg == FR_MAX_SEG) return false;
+      FrontSeg& G = P.seg[P.n_seg++];
+      G.col0 = Y.conv[c].coff; G.rows = C.f_out; G.nsrc = 1; G.ld = P.K;
+      G.off[0] = (uint32_t)C.w0;
+    }
+    if (Y.roff[s] >= 0) {
+      if (P.n_seg == FR_MAX_SEG) return false;
+      FrontSeg& G = P.seg[P.n_seg++];
+      G.col0 = Y.roff[s]; G.rows = Ls.out_dim[s]; G.nsrc = 0; G.ld = P.K;
+      for (int i = 0; i < Y.n_live; ++i) {
+        const hmp_conv_spec& C = Ls.convs[Y.live[i]];
+        if (C.dst != s) continue;
+        if (G.nsrc == FR_MAX_SRC) return false;
+        G.off[G.nsrc++] = (uint32_t)C.w1;
+      }
+      if (G.nsrc == 0) return false;
+    }
+  }
+  if (fa.n_prob == 0 || S.n_params >= ((int64_t)1 << 31)) return false;
+  // ---- plan parts
+  PlanBatch pb;
+  fill_plan_batch(n, b, pb);
+  int64_t E = 0;
+  for (int e = 0; e < pb.n; ++e) E += pb.j[e].E;
+  if (E > PS_MAX_EDGES) return false;
+  fa.n_jobs = pb.n;
+  fa.need_tpos = 0;
+  fa.plan_rc = plan_small_fits_rc(pb) ? 1 : 0;
+  fa.plan_blocks = plan_small_layout(pb, fa.part_start, fa.rows_per_part);
+  fa.ws = n->ws_base;
+  auto woff = [&](const void* p) -> uint32_t { return (uint32_t)((reinterpret_cast<const char*>(p) - n->ws_base) >> 2); };
+  if (n->ws_bytes >= ((size_t)1 << 34)) return false;  // 32-bit word offsets
+  for (int e = 0; e < pb.n; ++e) {
+    const PlanJob& J = pb.j[e];
+    FrontJob& F = fa.job[e];
+    F.ei = J.ei; F.E = (int)J.E; F.n_src = J.n_src; F.n_dst = J.n_dst;
+    F.rowptr = woff(J.rowptr); F.col = woff(J.col); F.eid = woff(J.eid);
+    F.t_rowptr = woff(J.t_rowptr); F.t_col = woff(J.t_col); F.t_eid = woff(J.t_eid);
+    F.tmp_in = woff(J.tmp_in); F.tmp_out = woff(J.tmp_out); F.pos_of_eid = woff(J.pos_of_eid); F.degf = woff(J.degf);
+  }
+  fa.status = &n->d_state->status;
+  // ---- pack blocks
+  fa.params = d_params;
+  fa.segs = n->d_pack_segs;
+  fa.pack_map = n->d_pack_map;
+  fa.pack_blocks = n->n_pack_blocks16;
+  fa.packed = n->d_packed;
+  fa.state = n->step_dev ? n->d_state : nullptr;
+  return true;
+}
+
 int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStream_t st) {
   HMP_TRY(check_batch(n, b));
   n->batch = *b;
@@ -735,17 +831,31 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   hipStream_t main_st = st;
   hipStream_t side = (n->use_branches && (n->branch_mask & 1)) ? n->side[0] : main_st;
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
-  {
+  n->fuse_now = fuse_small(n, b);
+  // Small batches, SAGE layer 0: projection (reading the stacked weights straight from the flat parameters), plan and pack
+  // are roles of ONE launch (front.hip) -- the plan, which has to read whole edge lists through single CUs, hides behind
+  // the projection tiles.
+  FrontArgs fa;
+  const bool front = n->fuse_now && build_front(n, b, d_params, fa);
+  if (front) {
+    Scope sc(n, KC_FRONT, main_st);
+    HMP_TRY(front_launch(fa, main_st));
+    for (int e = 0; e < n->ET; ++e) {  // what run_plan records on the host
+      hmp_plan& P = n->plan[e];
+      P.n_src = b->n_nodes[S.edge_src[e]]; P.n_dst = b->n_nodes[S.edge_dst[e]]; P.n_edges = b->n_edges[e];
+    }
+  } else {
     Scope sc(n, KC_PACK, side);
     HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
   }
   bool z_done = false;
-  n->fuse_now = fuse_small(n, b);
   for (int l = 0; l < n->L; ++l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
     st = (l == 0) ? side : main_st;
-    if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
+    if (l == 0 && front) {
+      // projection, plan and pack already ran in the front kernel
+    } else if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
       Scope sc(n, KC_GEMM_FWD, st);
       std::vector<GemmProblem> ps;
       for (int s = 0; s < n->T; ++s) {
@@ -763,7 +873,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
       HMP_TRY(gemm_many(ps, false, st, nullptr));
     }
     z_done = false;
-    if (l == 0) {
+    if (l == 0 && !front) {
       HMP_TRY(run_plan(n, b, main_st));
       if (side != main_st) HMP_TRY(fork_to(n, side, main_st));  // join
       st = main_st;
@@ -1055,7 +1165,30 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   } else {
     Scope sc(n, KC_GEMM_BWD, st);
     std::vector<int> ks;
-    HMP_TRY(gemm_many(wps, true, st, &ks));
+    bool direct = n->fuse_now;
+    if (direct) {  // register-direct TN kernel (one memory round trip per <= 192-node chunk); all-or-nothing per call
+      const char* tv = getenv("HMP_TN");  // 0: LDS-staged split-K kernel (tests)
+      if (tv && tv[0] == '0') direct = false;
+      for (size_t i = 0; i < wps.size() && direct; ++i)
+        if (wps[i].K > MAX_SLABS * 384) direct = false;
+      for (size_t base = 0; base < wps.size() && direct; base += GEMM_MAX_PROB) {
+        TnBatch tb;
+        memset(&tb, 0, sizeof(tb));
+        const size_t cnt = (wps.size() - base) < (size_t)GEMM_MAX_PROB ? (wps.size() - base) : (size_t)GEMM_MAX_PROB;
+        for (size_t i = 0; i < cnt; ++i) {
+          const GemmProblem& g = wps[base + i];
+          TnProblem& P = tb.p[tb.n++];
+          P.A = g.A; P.B = g.B; P.C = g.C; P.slab_stride = g.slab_stride;
+          P.M = g.M; P.N = g.N; P.K = g.K; P.lda = g.lda; P.ldb = g.ldb; P.ldc = g.ldc;
+          P.n_real = g.n_real; P.aug_ones = g.aug_ones;
+        }
+        int ok = 0;
+        HMP_TRY(gemm_tn_direct_launch(tb, MAX_SLABS, &ok, st));
+        HMP_CHECK_ARG(ok, "net: weight-gradient problem too deep for the direct kernel after the size check");
+        for (size_t i = 0; i < cnt; ++i) ks.push_back(tb.p[i].ksplit);
+      }
+    }
+    if (!direct) HMP_TRY(gemm_many(wps, true, st, &ks));
     for (size_t i = 0; i < wids.size(); ++i) n->dyn.n_slabs[wids[i]] = (unsigned char)ks[i];
   }
   {
@@ -1119,6 +1252,7 @@ extern "C" void hmp_net_destroy(hmp_net* n) {
     if (n->side[i]) (void)hipStreamDestroy(n->side[i]);
   if (n->d_pack_segs) (void)hipFree(n->d_pack_segs);
   if (n->d_pack_row_start) (void)hipFree(n->d_pack_row_start);
+  if (n->d_pack_map) (void)hipFree(n->d_pack_map);
   if (n->d_grad_segs) (void)hipFree(n->d_grad_segs);
   if (n->d_grad_elem_start) (void)hipFree(n->d_grad_elem_start);
   for (int l = 0; l < HMP_MAX_LAYERS; ++l)
@@ -1140,6 +1274,8 @@ extern "C" int hmp_net_bind_workspace(hmp_net* n, void* d_workspace, size_t byte
   HMP_CHECK_ARG(bytes >= need, "hmp_net_bind_workspace: %zu bytes given, %zu needed", bytes, need);
   for (int t = 0; t < n->T; ++t) n->cap_nodes[t] = cap_nodes[t];
   for (int e = 0; e < n->ET; ++e) n->cap_edges[e] = cap_edges[e];
+  n->ws_base = (char*)d_workspace;
+  n->ws_bytes = need;
   // zero once: padding columns of every buffer stay zero for the lifetime of the binding
   HMP_HIP(hipMemset(d_workspace, 0, need));
   HMP_TRY(build_gat_tables(n));

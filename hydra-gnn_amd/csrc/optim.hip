@@ -1,5 +1,5 @@
 // Loss, optimiser and the parameter <-> packed-operand shuffles around the layer kernels.
-#include "kernels.h"
+#include "device_fns.h"
 
 namespace hmp {
 
@@ -153,38 +153,7 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(DropCfg cfg, int n_ro
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ segs, const SegBlocks sb, const float* __restrict__ params,
                                                    float* __restrict__ packed, NetState* step_state) {
-  if (step_state && blockIdx.x == 0 && threadIdx.x == 0) step_state->step += 1;
-  int si = 0;
-  while (si + 1 < sb.n && (int)blockIdx.x >= sb.start[si + 1]) ++si;  // wave-uniform scan of the kernarg table
-  const PackSeg S = segs[si];
-  // one wavefront per (packed row, 64-column chunk): the attention folds (a C-long dot per element) get as many
-  // wavefronts as the plain copies instead of one block looping over everything
-  const int chunks = (S.ld_dst + 63) >> 6;
-  const int item = ((int)blockIdx.x - sb.start[si]) * 4 + (threadIdx.x >> 6);
-  const int r = item / chunks;
-  if (r >= S.rows_pad) return;
-  float* dst = packed + S.dst + (int64_t)r * S.ld_dst;
-  {
-    const int c = (item % chunks) * 64 + (threadIdx.x & 63);
-    if (c >= S.ld_dst) return;
-    float v = 0.f;
-    if (S.kind == PACK_SUM) {
-      if (r < S.rows && c < S.cols)
-        for (int q = 0; q < S.nsrc; ++q) v += params[S.src[q] + (int64_t)r * S.ld_src + c];
-    } else if (S.kind == PACK_HEADS) {
-      const int h = r / S.Cp, cc = r % S.Cp;
-      if (h < S.H && cc < S.C && c < S.cols) v = params[S.src[0] + (int64_t)(h * S.C + cc) * S.ld_src + c];
-    } else if (S.kind == PACK_ATTDOT) {  // row r = head
-      if (r < S.H && c < S.cols)
-        for (int cc = 0; cc < S.C; ++cc)
-          v += params[S.att + r * S.C + cc] * params[S.src[0] + (int64_t)(r * S.C + cc) * S.ld_src + c];
-    } else {  // PACK_ATTDOT_T: row r = edge-attribute dimension d, column c = head
-      if (r < S.rows && c < S.H)
-        for (int cc = 0; cc < S.C; ++cc)
-          v += params[S.att + c * S.C + cc] * params[S.src[0] + (int64_t)(c * S.C + cc) * S.ld_src + r];
-    }
-    dst[c] = v;
-  }
+  pack_block(segs, sb, params, packed, step_state, (int)blockIdx.x);
 }
 
 int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, NetState* step_state, hipStream_t st) {

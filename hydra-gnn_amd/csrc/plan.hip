@@ -9,9 +9,11 @@
 // to run although step (3) uses atomics.  (5) links every CSC entry to its CSR position.
 #include <cstdlib>
 
-#include "kernels.h"
+#include "plan_small.h"
 
 namespace hmp {
+
+KT_DEFINE(plan)
 
 __device__ __forceinline__ int find_job(const int64_t* start, int n, int64_t g) {
   int j = 0;
@@ -131,188 +133,12 @@ __global__ __launch_bounds__(256) void plan_link_kernel(const PlanBatch pb) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Small batches (all edge types together <= PS_MAX_EDGES edges): the whole build in ONE launch, no global atomics,
-// no counters to keep clean.  A 1024-thread block owns one (edge type, direction, row range) part: it reads ALL edges
-// of its type twice from L2 (a few 10^4 edges: a handful of iterations per thread) and keeps everything about its
-// <= PS_ROWS rows in LDS --
-//   pass 1  histogram of its rows (LDS atomics) + count of the edges that belong to earlier rows (-> its rowptr base)
-//   scan    exclusive scan of the histogram -> rowptr (global) and the local row starts
-//   pass 2  every edge of the part takes a slot in its row (LDS atomic cursor: arbitrary order inside the row)
-//   rank    one thread per slot counts the smaller edge ids of its row -> stable position, writes col / eid
-// The result is the same stable order as the multi-launch path (and bit-identical from run to run).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int PS_ROWS = 1024;        // rows per part
-constexpr int PS_TMP = 12 * 1024;    // edge slots of a part kept in LDS (parts with more edges use the global scratch)
-constexpr int PS_UB = 8;             // edges per thread in flight in the two passes over the edge list
-constexpr int64_t PS_MAX_EDGES = 65536;
-
-struct PlanSmallArgs {
-  PlanBatch pb;
-  int part_start[2 * HMP_MAX_EDGE_TYPES + 1];  // first block of (job, dir)
-  int rows_per_part[2 * HMP_MAX_EDGE_TYPES];
-};
-
-// 130 KB of LDS (a gfx950 workgroup may take up to 160 KB): one block per CU, ~10-30 blocks per launch
+template <bool RC>
 __global__ __launch_bounds__(1024) void plan_small_kernel(const PlanSmallArgs a, int* status) {
-  __shared__ int cnt[PS_ROWS];
-  __shared__ int lrow[PS_ROWS + 1];
-  __shared__ int ltmp[PS_TMP];             // edge id per slot
-  __shared__ int lcol[PS_TMP];             // the other endpoint of that edge
-  __shared__ unsigned short lkey[PS_TMP];  // row (relative to the part) of the slot
-  __shared__ int wsum[16];
-  __shared__ int s_base, s_total;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  int jd = 0;
-  while (jd + 1 < 2 * a.pb.n && (int)blockIdx.x >= a.part_start[jd + 1]) ++jd;
-  const PlanJob& J = a.pb.j[jd >> 1];
-  const int dir = jd & 1;
-  const int part = (int)blockIdx.x - a.part_start[jd];
-  const int n_rows = dir ? J.n_src : J.n_dst;
-  const int rpp = a.rows_per_part[jd];
-  const int r0 = part * rpp;
-  const int r1 = min(n_rows, r0 + rpp);
-  const int nr = max(r1 - r0, 0);
-  const bool last_part = (int)blockIdx.x + 1 == a.part_start[jd + 1];
-  const int E = (int)J.E;
-  const int64_t* __restrict__ es = J.ei;
-  const int64_t* __restrict__ ed = J.ei + J.E;
-  const int n_src = J.n_src, n_dst = J.n_dst;
-
-  for (int i = tid; i < PS_ROWS; i += 1024) cnt[i] = 0;
-  __syncthreads();
-  // pass 1: PS_UB (clamped) edges per thread in flight
-  int below = 0, bad = 0;
-  for (int e0 = tid; e0 < E; e0 += PS_UB * 1024) {
-    int64_t sv[PS_UB], dv[PS_UB];
-#pragma unroll
-    for (int u = 0; u < PS_UB; ++u) {
-      const int e = min(e0 + u * 1024, E - 1);
-      sv[u] = es[e];
-      dv[u] = ed[e];
-    }
-#pragma unroll
-    for (int u = 0; u < PS_UB; ++u) {
-      if (e0 + u * 1024 >= E) break;
-      const int64_t s = sv[u], d = dv[u];
-      if (s < 0 || s >= n_src || d < 0 || d >= n_dst) { bad = 1; continue; }
-      const int key = (int)(dir ? s : d);
-      if (key < r0) ++below;
-      else if (key < r1) atomicAdd(&cnt[key - r0], 1);
-    }
-  }
-  if (bad && status && part == 0 && dir == 0) atomicOr(status, 1);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
-  if (lane == 0) wsum[w] = below;
-  __syncthreads();
-  if (tid == 0) {
-    int b = 0;
-    for (int q = 0; q < 16; ++q) b += wsum[q];
-    s_base = b;
-  }
-  __syncthreads();
-  const int base = s_base;
-  // scan (one row per thread)
-  {
-    const int v = tid < nr ? cnt[tid] : 0;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o);
-      if (lane >= o) x += y;
-    }
-    __syncthreads();  // everybody has read wsum / s_base
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < w; ++q) woff += wsum[q];
-    const int excl = woff + x - v;
-    if (tid < nr) {
-      lrow[tid] = excl;
-      (dir ? J.t_rowptr : J.rowptr)[r0 + tid] = base + excl;
-      if (!dir && J.degf) J.degf[r0 + tid] = (float)(v > 1 ? v : 1);
-      cnt[tid] = 0;  // becomes the row cursor of pass 2
-    }
-    if (tid == 1023) s_total = woff + x;
-    __syncthreads();
-    if (tid == 0) {
-      lrow[nr] = s_total;
-      if (last_part) (dir ? J.t_rowptr : J.rowptr)[n_rows] = base + s_total;
-    }
-  }
-  __syncthreads();
-  const int total = s_total;
-  const bool in_lds = total <= PS_TMP;
-  int* __restrict__ gtmp = (dir ? J.tmp_out : J.tmp_in) + base;
-  // pass 2: every edge of the part takes a slot in its row
-  for (int e0 = tid; e0 < E; e0 += PS_UB * 1024) {
-    int64_t sv[PS_UB], dv[PS_UB];
-#pragma unroll
-    for (int u = 0; u < PS_UB; ++u) {
-      const int e = min(e0 + u * 1024, E - 1);
-      sv[u] = es[e];
-      dv[u] = ed[e];
-    }
-#pragma unroll
-    for (int u = 0; u < PS_UB; ++u) {
-      const int e = e0 + u * 1024;
-      if (e >= E) break;
-      const int64_t s = sv[u], d = dv[u];
-      if (s < 0 || s >= n_src || d < 0 || d >= n_dst) continue;
-      const int key = (int)(dir ? s : d);
-      if (key < r0 || key >= r1) continue;
-      const int slot = lrow[key - r0] + atomicAdd(&cnt[key - r0], 1);
-      if (in_lds) {
-        ltmp[slot] = e;
-        lcol[slot] = (int)(dir ? d : s);
-        lkey[slot] = (unsigned short)(key - r0);
-      } else {
-        gtmp[slot] = e;
-      }
-    }
-  }
-  __syncthreads();
-  // rank: one thread per slot counts the smaller edge ids of its row
-  if (in_lds) {
-    for (int q = tid; q < total; q += 1024) {
-      const int r = lkey[q];
-      const int b = lrow[r], en = lrow[r + 1];
-      const int mine = ltmp[q];
-      int rank = 0;
-      for (int i = b; i < en; ++i) rank += (ltmp[i] < mine) ? 1 : 0;
-      const int pos = base + b + rank;
-      if (dir == 0) {
-        J.eid[pos] = mine;
-        J.col[pos] = lcol[q];
-        if (a.pb.need_tpos) J.pos_of_eid[mine] = pos;
-      } else {
-        if (a.pb.need_tpos) J.t_eid[pos] = mine;
-        J.t_col[pos] = lcol[q];
-      }
-    }
-  } else {
-    for (int q = tid; q < total; q += 1024) {
-      int lo = 0, hi = nr - 1;  // row of slot q: last r with lrow[r] <= q
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (lrow[mid] <= q) lo = mid; else hi = mid - 1;
-      }
-      const int b = lrow[lo], en = lrow[lo + 1];
-      const int mine = gtmp[q];
-      int rank = 0;
-      for (int i = b; i < en; ++i) rank += (gtmp[i] < mine) ? 1 : 0;
-      const int pos = base + b + rank;
-      if (dir == 0) {
-        J.eid[pos] = mine;
-        J.col[pos] = (int)es[mine];
-        if (a.pb.need_tpos) J.pos_of_eid[mine] = pos;
-      } else {
-        if (a.pb.need_tpos) J.t_eid[pos] = mine;
-        J.t_col[pos] = (int)ed[mine];
-      }
-    }
-  }
+  __shared__ __attribute__((aligned(16))) char lds[PS_LDS_BYTES];
+  KT(0);
+  plan_small_block<RC>(a, status, (int)blockIdx.x, lds);
+  KT(5);
 }
 
 size_t plan_scratch_ints(int64_t E, int n_src, int n_dst) {
@@ -356,17 +182,9 @@ int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
   if (small_mode == 1 || (small_mode < 0 && E <= PS_MAX_EDGES)) {
     PlanSmallArgs a;
     a.pb = pb;
-    int blocks = 0;
-    for (int jd = 0; jd < 2 * pb.n; ++jd) {
-      const PlanJob& J = pb.j[jd >> 1];
-      const int nrows = (jd & 1) ? J.n_src : J.n_dst;
-      const int parts = nrows > 0 ? cdiv(nrows, PS_ROWS) : 1;
-      a.part_start[jd] = blocks;
-      a.rows_per_part[jd] = nrows > 0 ? cdiv(nrows, parts) : 1;
-      blocks += parts;
-    }
-    a.part_start[2 * pb.n] = blocks;
-    hipLaunchKernelGGL(plan_small_kernel, dim3(blocks), dim3(1024), 0, st, a, d_status);
+    const int blocks = plan_small_layout(pb, a.part_start, a.rows_per_part);
+    if (plan_small_fits_rc(pb)) hipLaunchKernelGGL(plan_small_kernel<true>, dim3(blocks), dim3(1024), 0, st, a, d_status);
+    else hipLaunchKernelGGL(plan_small_kernel<false>, dim3(blocks), dim3(1024), 0, st, a, d_status);
     HMP_LAUNCH_CHECK();
     if (pb.need_tpos && E > 0) {
       const int lg = (int)(cdiv(E, 256) < 2048 ? cdiv(E, 256) : 2048);

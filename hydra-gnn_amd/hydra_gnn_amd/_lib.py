@@ -10,12 +10,13 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhydra_mp.so")
+# HMP_LIB selects another build of the same ABI (the profiling variant libhydra_mp_kt.so from `make KTIME=1`)
+LIB_PATH = os.environ.get("HMP_LIB") or os.path.join(HERE, "libhydra_mp.so")
 
 MAX_NODE_TYPES, MAX_EDGE_TYPES, MAX_LAYERS, MAX_CONVS = 8, 16, 8, 16
-N_KCLASS = 12
+N_KCLASS = 13
 KCLASS_NAMES = ["plan", "pack", "gemm_fwd", "aggregate_fwd", "loss", "aggregate_bwd", "gemm_bwd", "grad_reduce",
-                "adam", "gat_fwd", "gat_bwd", "pool"]
+                "adam", "gat_fwd", "gat_bwd", "pool", "front"]
 CONV_SAGE, CONV_GAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 

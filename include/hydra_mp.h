@@ -271,8 +271,9 @@ int hmp_timer_elapsed_ms(hmp_timer* t, float* ms); /* synchronises on the stop e
 void hmp_timer_destroy(hmp_timer* t);
 /* per-kernel-class device time accumulated by the executor when profiling is on (HIP events around
  * every launch of that class on the executor's stream).  classes: 0 plan, 1 pack, 2 gemm_fwd,
- * 3 aggregate_fwd, 4 loss, 5 aggregate_bwd, 6 gemm_bwd, 7 grad_reduce, 8 adam, 9 gat_fwd, 10 gat_bwd */
-#define HMP_N_KCLASS 12
+ * 3 aggregate_fwd, 4 loss, 5 aggregate_bwd, 6 gemm_bwd, 7 grad_reduce, 8 adam, 9 gat_fwd, 10 gat_bwd, 11 pool,
+ * 12 front (layer-0 projection + plan + pack in one launch, small batches) */
+#define HMP_N_KCLASS 13
 int hmp_net_profile(hmp_net* net, int32_t enable);
 int hmp_net_profile_read(hmp_net* net, float* ms_sum /*[HMP_N_KCLASS]*/, int32_t* launches /*[HMP_N_KCLASS]*/);
 

@@ -176,3 +176,51 @@ def test_htree_sequences_agree_and_pool_path_finalises_loss():
             torch.testing.assert_close(res["1"][2][k], g, atol=2e-6, rtol=2e-5, msg=lambda m: f"{k}: {m}")
     np.testing.assert_allclose(steps["1"], steps["0"], rtol=1e-5, atol=1e-6)
     assert steps["1"][-1] < steps["1"][0]
+
+
+@pytest.mark.parametrize("var,kw_over", [("HMP_FRONT", {}), ("HMP_TN", {}), ("HMP_FRONT", {"hidden_dim": 128, "num_layers": 4})])
+def test_front_kernel_and_direct_weight_gradient_agree_with_separate_launches(monkeypatch, var, kw_over):
+    """HMP_FRONT=0: pack, layer-0 projection and plan as separate launches; HMP_TN=0: LDS-staged split-K weight gradients"""
+    kw = dict(SAGE_KW, **kw_over)
+    batch = workloads.config2_batch(8)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv(var, mode)
+        with fuse_env("1"):
+            _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+            res[mode] = run_fwd_bwd(net, batch, "rooms")
+            step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, use_graph=False)
+            gb = batch.to(DEV)
+            for _ in range(3):
+                step(gb, gb["rooms"].y)
+            res[mode] += (step.loss(), {k: p.detach().clone() for k, p in net.named_parameters()})
+    monkeypatch.delenv(var)
+    torch.testing.assert_close(res["1"][0], res["0"][0], atol=2e-6, rtol=2e-6)
+    for k, g in res["0"][2].items():
+        if g is not None:
+            torch.testing.assert_close(res["1"][2][k], g, atol=2e-6, rtol=2e-5, msg=lambda m: f"{k}: {m}")
+    assert abs(res["1"][3] - res["0"][3]) < 1e-5
+    for k, p0 in res["0"][4].items():
+        d = (res["1"][4][k] - p0).abs()
+        assert float(d.max()) <= 3 * 0.002 * 2.1, k
+        assert float((d > 2e-5).double().mean()) < 0.01, k
+
+
+def test_front_kernel_odd_shapes():
+    """rooms-only tiles, a node type with K = 6 (one ragged stage), hidden 40 (segments that straddle 64-column tiles)"""
+    kw = dict(SAGE_KW, hidden_dim=40)
+    batch = workloads.config2_batch(3)
+    with fuse_env("1"):
+        ora, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+        pred, loss, grads = run_fwd_bwd(net, batch, "rooms")
+    o64 = copy.deepcopy(ora).double()
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    pred_ref = o64(b64)
+    y = batch["rooms"].y
+    o64.loss(pred_ref, y, y != 25).backward()
+    torch.testing.assert_close(pred.cpu().double(), pred_ref.detach(), atol=ATOL, rtol=RTOL)
+    for name, p in o64.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(grads[name].cpu().double(), p.grad, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
