@@ -93,8 +93,11 @@ def make_workload(args, rank):
 # ------------------------------------------------------------------------------------------------------------
 # algorithmic (compulsory) traffic / flops of one training step, per kernel family
 # ------------------------------------------------------------------------------------------------------------
-def step_costs(net, holder):
-    """bytes/flops per kernel family for ONE step, from the shapes of this batch (fp32 = 4 bytes)."""
+def step_costs(net, holder, fused):
+    """Algorithmic (compulsory) bytes / flops of ONE step per kernel class, from the shapes of this batch (fp32 = 4 bytes;
+    formulas: DESIGN.md section 5).  `fused` = the small-batch launch sequence ran (front kernel,
+    projections / input gradients inside the aggregation kernels): the GEMM terms are then charged to the kernels that
+    execute them."""
     from hydra_gnn_amd._lib import CONV_GAT
 
     nn_ = dict(zip(net.node_types, holder.n_nodes))
@@ -103,7 +106,24 @@ def step_costs(net, holder):
     for layer in net.layers:
         dims.append(dict(layer.out_dims))
     al4 = lambda v: (v + 3) // 4 * 4
-    cost = {k: {"bytes": 0.0, "flops": 0.0, "launches": 0} for k in ("gemm", "agg_fwd", "agg_bwd", "gat_fwd", "gat_bwd")}
+    keys = ("front", "plan", "pack", "gemm_fwd", "agg_fwd", "agg_bwd", "gemm_bwd", "gat_fwd", "gat_bwd", "grad_reduce")
+    cost = {k: {"bytes": 0.0, "flops": 0.0, "launches": 0} for k in keys}
+
+    def add(k, by, fl):
+        cost[k]["bytes"] += by
+        cost[k]["flops"] += fl
+
+    L = len(net.layers)
+    n_params = float(net.n_active)
+    E_all = float(sum(holder.n_edges))
+    N_all = float(sum(holder.n_nodes))
+    plan_b = 16.0 * E_all + 24.0 * E_all + 8.0 * N_all
+    pack_b = 8.0 * n_params
+    add("front" if fused else "plan", plan_b, 0.0)
+    add("front" if fused else "pack", pack_b, 0.0)
+    cost["front" if fused else "plan"]["launches"] += 1
+    if not fused:
+        cost["pack"]["launches"] += 1
     for l, layer in enumerate(net.layers):
         live = [c for c in layer.convs if c.active]
         gat = live[0].kind == CONV_GAT
@@ -119,14 +139,19 @@ def step_costs(net, holder):
                 ncols[c.edge_type[0]] += al4(c.f_out)
             for t in dsts:
                 ncols[t] += al4(layer.out_dims[t])
-        # forward projection Z_s = H_s * Wp_s^T
+        # forward projection Z_s = H_s * Wp_s^T: front kernel (layer 0), previous layer's aggregation kernel (fused), else GEMM
+        proj_cls = "gemm_fwd"
+        if fused and not gat:
+            proj_cls = "front" if l == 0 else "agg_fwd"
+        elif fused and gat and l > 0 and net.layers[l - 1].convs[0].kind != CONV_GAT:
+            proj_cls = "agg_fwd"
         for s, nc in ncols.items():
             if nc == 0:
                 continue
             N, F = nn_[s], dims[l][s]
-            cost["gemm"]["bytes"] += 4.0 * (N * F + nc * F + N * nc)
-            cost["gemm"]["flops"] += 2.0 * N * F * nc
-        cost["gemm"]["launches"] += 1
+            add(proj_cls, 4.0 * ((N * F if proj_cls != "agg_fwd" else 0) + nc * F + N * nc), 2.0 * N * F * nc)
+        if proj_cls == "gemm_fwd":
+            cost["gemm_fwd"]["launches"] += 1
         if gat:
             by = fl = 0.0
             for c in live:
@@ -136,11 +161,9 @@ def step_costs(net, holder):
                 by += 4.0 * (nn_[t] + 1) + 4.0 * E + (12.0 * E if c.gat.get("edge_dim") else 0.0) + 4.0 * nn_[s] * (H * Cc + H) + 4.0 * nn_[t] * H
                 fl += E * H * (2.0 * Cc + 12.0)
             by += sum(4.0 * nn_[t] * layer.out_dims[t] for t in dsts)
-            cost["gat_fwd"]["bytes"] += by
-            cost["gat_fwd"]["flops"] += fl
+            add("gat_fwd", by, fl)
             cost["gat_fwd"]["launches"] += 1
-            cost["gat_bwd"]["bytes"] += 2.0 * by + sum(16.0 * 8 * ne[c.edge_type] for c in live)
-            cost["gat_bwd"]["flops"] += 2.0 * fl
+            add("gat_bwd", 2.0 * by + sum(16.0 * 8 * ne[c.edge_type] for c in live), 2.0 * fl)
             cost["gat_bwd"]["launches"] += 2
         else:
             # fused aggregation: indices + each projected source segment once + root + out
@@ -151,26 +174,28 @@ def step_costs(net, holder):
                     if c.edge_type[2] != t:
                         continue
                     b += 4.0 * (nn_[t] + 1) + 4.0 * ne[c.edge_type] + 4.0 * nn_[c.edge_type[0]] * Fo
-                cost["agg_fwd"]["bytes"] += b
-                cost["agg_fwd"]["flops"] += sum(ne[c.edge_type] * Fo for c in live if c.edge_type[2] == t)
+                add("agg_fwd", b, sum(ne[c.edge_type] * Fo for c in live if c.edge_type[2] == t))
             cost["agg_fwd"]["launches"] += 1
             # backward: transposed aggregation (same compulsory traffic as forward, mirrored)
-            cost["agg_bwd"]["bytes"] += sum(
-                4.0 * (nn_[c.edge_type[0]] + 1) + 8.0 * ne[c.edge_type] + 4.0 * nn_[c.edge_type[2]] * al4(c.f_out)
-                + 4.0 * nn_[c.edge_type[0]] * al4(c.f_out) for c in live) + sum(8.0 * nn_[t] * al4(layer.out_dims[t]) for t in dsts)
-            cost["agg_bwd"]["flops"] += sum(2.0 * ne[c.edge_type] * al4(c.f_out) for c in live)
+            add("agg_bwd", sum(4.0 * (nn_[c.edge_type[0]] + 1) + 8.0 * ne[c.edge_type] + 4.0 * nn_[c.edge_type[2]] * al4(c.f_out)
+                               + 4.0 * nn_[c.edge_type[0]] * al4(c.f_out) for c in live) + sum(8.0 * nn_[t] * al4(layer.out_dims[t]) for t in dsts),
+                sum(2.0 * ne[c.edge_type] * al4(c.f_out) for c in live))
             cost["agg_bwd"]["launches"] += 1
         # weight gradient dWp = dZ^T [H | 1]  and (l > 0) input gradient dH = dZ * Wp
+        dx_cls = "agg_bwd" if (fused and not gat) else "gemm_bwd"
         for s, nc in ncols.items():
             if nc == 0:
                 continue
             N, F = nn_[s], dims[l][s]
-            cost["gemm"]["bytes"] += 4.0 * (N * nc + N * F + nc * (F + 1))
-            cost["gemm"]["flops"] += 2.0 * N * (F + 1) * nc
+            add("gemm_bwd", 4.0 * (N * nc + N * F + nc * (F + 1)), 2.0 * N * (F + 1) * nc)
             if l > 0:
-                cost["gemm"]["bytes"] += 4.0 * (N * nc + nc * F + 2 * N * F)
-                cost["gemm"]["flops"] += 2.0 * N * F * nc
-        cost["gemm"]["launches"] += 2 if l > 0 else 1
+                add(dx_cls, 4.0 * ((N * nc if dx_cls == "gemm_bwd" else 0) + nc * F + 2 * N * F), 2.0 * N * F * nc)
+        if l > 0 and dx_cls == "gemm_bwd":
+            cost["gemm_bwd"]["launches"] += 1
+    cost["gemm_bwd"]["launches"] += 1 if fused else L  # weight gradients: one merged launch when fused
+    # gradient un-pack (reads the split-K slabs once) + Adam (p, g, m, v read; p, m, v written)
+    add("grad_reduce", 4.0 * n_params * 2 + 28.0 * n_params, 12.0 * n_params)
+    cost["grad_reduce"]["launches"] += 1
     return cost
 
 
@@ -274,19 +299,26 @@ def main():
         _lib.check(nat._lib.hmp_net_profile_read(nat._handle, ms, ln))
         _lib.check(nat._lib.hmp_net_profile(nat._handle, 0))
         per = {name: (ms[i], ln[i]) for i, name in enumerate(_lib.KCLASS_NAMES)}
-        cost = step_costs(nat, prof_step._holder)
+        fused = per["front"][1] > 0
+        cost = step_costs(nat, prof_step._holder, fused)
         fam = {
-            "gemm": ("gemm_kernel (fp32 MFMA 32x32x2, grouped)", per["gemm_fwd"][0] + per["gemm_bwd"][0], per["gemm_fwd"][1] + per["gemm_bwd"][1]),
-            "agg_fwd": ("agg_fwd_kernel (fused SAGE aggregation)", *per["aggregate_fwd"]),
-            "agg_bwd": ("agg_bwd_kernel (transposed aggregation)", *per["aggregate_bwd"]),
+            "front": ("front_kernel (layer-0 projection tiles + plan parts + pack blocks, one launch)", *per["front"]),
+            "gemm_fwd": ("gemm_kernel (fp32 MFMA 32x32x2, grouped, LDS-staged)", *per["gemm_fwd"]),
+            "gemm_bwd": ("gemm_tn_direct_kernel (weight gradients, fp32 MFMA, register-direct)" if fused else
+                         "gemm_kernel (fp32 MFMA 32x32x2, grouped, LDS-staged)", *per["gemm_bwd"]),
+            "agg_fwd": ("agg_proj_fwd_kernel / agg_fwd_kernel (SAGE aggregation + next projection / + masked CE)" if fused else
+                        "agg_fwd_kernel (fused SAGE aggregation)", *per["aggregate_fwd"]),
+            "agg_bwd": ("agg_bwd_dx_kernel / agg_bwd_kernel (transposed aggregation + input-gradient GEMM)" if fused else
+                        "agg_bwd_kernel (transposed aggregation)", *per["aggregate_bwd"]),
             "gat_fwd": ("gat_fwd_kernel (edge softmax + aggregation)", *per["gat_fwd"]),
             "gat_bwd": ("gat_bwd1/2_kernel", *per["gat_bwd"]),
+            "grad_reduce": ("grad_reduce_kernel (slab reduction + Adam)", per["grad_reduce"][0] + per["adam"][0], per["grad_reduce"][1]),
         }
         table = {}
         for k, (name, tot_ms, launches) in fam.items():
-            if launches == 0 or cost[k]["launches"] == 0:
+            if launches == 0 or cost[k]["bytes"] == 0:
                 continue
-            # a profiling scope may cover several launches (GAT backward = 2 kernels; > 16 GEMM problems = 2 launches)
+            # a profiling scope may cover several launches (GAT backward = 2 kernels; > 8 GEMM problems = 2 launches)
             avg_us = 1e3 * tot_ms / launches
             by = cost[k]["bytes"] * prof_steps / launches
             fl = cost[k]["flops"] * prof_steps / launches
@@ -299,7 +331,7 @@ def main():
             d = table[dom]
             t_hbm = d["alg_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
             t_mfma = d["alg_flops_per_launch"] / (MFMA_F32_PEAK_TF * 1e12)
-            if dom == "gemm" and t_mfma >= t_hbm:
+            if dom.startswith("gemm") and t_mfma >= t_hbm:
                 out["roofline"] = {"kernel": d["kernel"], "bound": "mfma", "achieved": d["TFLOPs"], "peak": MFMA_F32_PEAK_TF,
                                    "unit": "TFLOP/s", "frac": round(d["TFLOPs"] / MFMA_F32_PEAK_TF, 5), "traffic": None,
                                    "avg_launch_us": d["avg_us"]}
@@ -307,6 +339,9 @@ def main():
                 out["roofline"] = {"kernel": d["kernel"], "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(d["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
                                    "avg_launch_us": d["avg_us"]}
+            out["roofline"]["note"] = ("launch/latency-bound regime: the whole step moves ~%.0f MB; every kernel is a chain of ~2 us "
+                                       "dependent memory round trips (cold L2 after each kernel boundary), see DESIGN.md section 6"
+                                       % (sum(c["bytes"] for c in cost.values()) / 1e6)) if args.config != 5 else "bandwidth regime"
             out["roofline_all"] = table
             # HBM traffic of the dominant family from the committed PMC passes of this same command (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_summary.py)
@@ -314,8 +349,9 @@ def main():
 
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_cfg{args.config}.json")))
             if pmc:
-                key = {"gemm": "gemm_kernel", "agg_fwd": "agg_fwd_kernel", "agg_bwd": "agg_bwd_kernel",
-                       "gat_fwd": "gat_fwd_kernel", "gat_bwd": "gat_bwd"}[dom]
+                key = {"front": "front_kernel", "gemm_fwd": "gemm_kernel", "gemm_bwd": "gemm_tn_direct_kernel" if fused else "gemm_kernel",
+                       "agg_fwd": "agg_proj_fwd_kernel" if fused else "agg_fwd_kernel", "agg_bwd": "agg_bwd_dx_kernel" if fused else "agg_bwd_kernel",
+                       "gat_fwd": "gat_fwd_kernel", "gat_bwd": "gat_bwd", "grad_reduce": "grad_reduce_kernel"}[dom]
                 ks = [v for k, v in json.load(open(pmc[-1]))["kernels"].items() if key in k]
                 nd = sum(v["dispatches"] for v in ks)
                 if nd:

@@ -346,7 +346,24 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
   const AggDst& D = a.d[ti];
   const int row0 = ((int)blockIdx.x - D.block_start) * TM;
   const int c0 = (threadIdx.x % GS) * 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = lane & 15, kq = lane >> 4;
   KT(0);
+  // The weights of the projection do not depend on the aggregation: request the first PT column tiles of this wave (first
+  // 64-deep k trip each) BEFORE the gather, so their round trip (every block pulls the whole Wp through its CU, ~25 GB/s)
+  // overlaps the three round trips of the gather instead of following them.
+  constexpr int PT = 3;
+  float4 pre[PT][4];
+  const int n_ct = D.pw ? (D.pncols + 15) >> 4 : 0;
+  if (D.pw) {  // block-uniform
+#pragma unroll
+    for (int it = 0; it < PT; ++it) {
+      const int col = min((w + 4 * it) * 16 + n, D.pncols - 1);  // clamped: tiles past n_ct are never used
+      const float* wrow = D.pw + (int64_t)col * D.pldw;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pre[it][u] = *reinterpret_cast<const float4*>(wrow + min(16 * u, D.pK - 16) + 4 * kq);
+    }
+  }
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int m = p * RPP + threadIdx.x / GS;
@@ -362,10 +379,8 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
   if (D.pw == nullptr) return;  // block-uniform: this node type is not read by the next layer
   __syncthreads();
   KT(1);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n = lane & 15, kq = lane >> 4;
-  const int n_ct = (D.pncols + 15) >> 4;
-  for (int ct = w; ct < n_ct; ct += 4) {
+  // one 16-column tile: bv0 = prefetched weights of the first k trip (null: load them here)
+  auto tile = [&](int ct, const float4* bv0) {
     const int col = ct * 16 + n;
     const float* wrow = D.pw + (int64_t)min(col, D.pncols - 1) * D.pldw;  // clamped: padded columns are never stored
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -373,7 +388,8 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
     for (int kb = 0; kb < D.pK; kb += 64) {
       float4 bv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bv[u] = *reinterpret_cast<const float4*>(wrow + min(kb + 16 * u, D.pK - 16) + 4 * kq);
+      for (int u = 0; u < 4; ++u)
+        bv[u] = (bv0 && kb == 0) ? bv0[u] : *reinterpret_cast<const float4*>(wrow + min(kb + 16 * u, D.pK - 16) + 4 * kq);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (kb + 16 * u >= D.pK) break;
@@ -392,7 +408,11 @@ __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
         if (row < D.n_rows) D.pz[(int64_t)row * D.pldz + col] = acc[r];
       }
     }
-  }
+  };
+#pragma unroll
+  for (int it = 0; it < PT; ++it)
+    if (w + 4 * it < n_ct) tile(w + 4 * it, pre[it]);
+  for (int ct = w + 4 * PT; ct < n_ct; ct += 4) tile(ct, nullptr);
   KT(2);
 }
 
@@ -535,7 +555,11 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   const TAggSrc& S = a.s[si];
   const int row0 = ((int)blockIdx.x - S.block_start) * TM;
   const int c0 = (threadIdx.x % GS) * VEC;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nn = lane & 15, kq = lane >> 4;
+  const int K = S.ncols;
   KT(8);
+  constexpr int WB = 48;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int m = p * RPP + threadIdx.x / GS;
@@ -618,9 +642,6 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   if (S.xw == nullptr) return;  // block-uniform
   __syncthreads();
   KT(9);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nn = lane & 15, kq = lane >> 4;
-  const int K = S.ncols;
   const int n_ct = (S.xN + 15) >> 4;
   for (int ct = w; ct < n_ct; ct += 4) {
     const int col = ct * 16 + nn;
@@ -628,8 +649,8 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     const float* hp = Hs + kq * LDH + nn;                                  // A operand: row m = lane & 15 of the tile
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // 48 k-steps (192 stacked columns) per trip: the (clamped) weight loads are all in flight together, then the MFMA
-    // chain runs -- one L2 round trip for the typical stacked width instead of one per 8 steps
-    constexpr int WB = 48;
+    // chain runs -- one L2 round trip for the typical stacked width.  (Requesting them before the gather was measured
+    // SLOWER, +1 us: 48 scalar loads per lane queue in front of the gather's own loads.)
     for (int kb = 0; kb < K; kb += 4 * WB) {
       float bv[WB];
 #pragma unroll
