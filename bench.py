@@ -49,11 +49,15 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="hipGraph replay instead of eager launches (eager is faster on ROCm 7.2: "
                     "graph replay adds ~3 us per node, the eager chain runs back to back)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
+                    help="compute mode of the large GEMMs (default: bf16 for config 5 as BASELINE.json names it, fp32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = DEFAULT_BATCH[a.config]
+    if a.precision is None:
+        a.precision = "bf16" if a.config == 5 else "fp32"
     if a.steps is None:
         a.steps = 200 if a.config != 5 else 10
     if a.warmup is None:
@@ -86,8 +90,8 @@ def make_workload(args, rank):
               dropout=0.25)
     g = workloads.big_hetero_graph(n_obj=args.big_objects, n_rooms=max(args.big_objects // 100, 1), seed=workloads.BASE_SEED + 5 + rank)
     return kw, "HeterogeneousNetwork", g, "rooms", (
-        f"BASELINE configs[4] in fp32: ONE synthetic hetero graph per rank, {args.big_objects} objects, "
-        f"{max(args.big_objects // 100, 1)} rooms, in-degree 16, 3-layer HeteroConv(SAGE) hidden 256 (bf16 storage not built yet)")
+        f"BASELINE configs[4]: ONE synthetic hetero graph per rank, {args.big_objects} objects, {max(args.big_objects // 100, 1)} rooms, "
+        f"in-degree 16, 3-layer HeteroConv(SAGE) hidden 256; projections in {args.precision} MFMA with fp32 accumulation, fp32 storage")
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -223,6 +227,7 @@ def main():
     torch.manual_seed(1234)  # identical initial weights on every rank
     net = getattr(hmodels, cls_name)(**model_kw).to(dev)
     net.train()
+    net.native().set_compute(args.precision)
     batch = batch_cpu.to(dev)
     labels = batch[label_type].y
     step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=20250225, use_graph=args.graph,
@@ -266,7 +271,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands; fp32 storage and accumulation)",
         "data": "synthetic",
         "config": {
             "workload": workload + "; training step = CSR/CSC plan + fwd + masked CE + bwd + flat-grad all-reduce + Adam",

@@ -368,15 +368,18 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm: %d problems", gb.n);
   int64_t tiles64 = 0;
+  double work = 0.0;
   int max_k = 0;
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative size");
     tiles64 += (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
+    work += (double)p.M * p.N * p.K;
     max_k = p.K > max_k ? p.K : max_k;
   }
-  // big problems: 64x64 tiles; small ones: 32x32 tiles with in-block K split and deep K stages
-  if (tiles64 >= 1024) return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
+  // big problems (many tiles, or few tiles over a very deep K: the weight gradients of a 10^6-node graph): 64x64 tiles;
+  // small ones: 32x32 tiles with in-block K split and deep K stages
+  if (tiles64 >= 1024 || work >= 1e9) return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
   if (max_k <= 64) return launch_cfg<1, 1, 64>(gb, want_split, max_slabs, st);
   return launch_cfg<1, 1, 128>(gb, want_split, max_slabs, st);
 }

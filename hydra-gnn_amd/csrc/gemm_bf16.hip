@@ -1,0 +1,304 @@
+// K2, bf16 compute variant for LARGE batches (BASELINE config 5: hidden 256, 10^6 nodes): grouped GEMM on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// Storage stays fp32 (activations, gradients, weights): operands are read as fp32, rounded to bf16 (round to nearest
+// even, v_cvt_pk_bf16_f32) on their way into LDS, and multiplied on the bf16 matrix pipe (2.5 PFLOP/s dense against
+// 157 TFLOP/s for fp32 MFMA), so these GEMMs become HBM-bound on their fp32 operands instead of MFMA-bound.  This is an
+// explicit precision mode (hmp_net_spec.compute_bf16): results differ from the fp32 path by bf16 input rounding
+// (~2^-9 relative per product), so it is NOT used for the 1e-5 parity configurations.
+//
+// Block = 4 waves, tile 128x128, K stage 32; every wave owns a 64x64 quadrant = 2x2 MFMA tiles (64 accumulator
+// registers).  LDS images are [row][k] in bf16 with a pitch of 40 elements (80 bytes: 16-byte aligned rows), so an MFMA
+// operand (8 consecutive k of one row) is one ds_read_b128.  A k-contiguous operand ([row][k] in memory) is loaded as
+// float4 along k (one 8-byte LDS write each) into a [row][k] image.  A row-contiguous operand ([k][row]: the weight-
+// gradient form, both operands) is loaded as float4 along rows into the NATURAL [k][row] image (8-byte writes) and
+// transposed by the hardware on the way out: ds_read_b64_tr_b16 hands every lane 4 consecutive k of its row, two of them
+// make one MFMA operand.  (Transposing on the way IN cost 16-way bank conflicts with 2-byte column writes -- 18 ms for the
+// config-5 weight gradients -- and 37 ms with 4-byte lane-per-row global loads.)  The next stage's global loads are
+// issued before the current stage's MFMAs.
+//
+// Forms: NT (x * W^T), NN (dZ * W, optional activation-derivative epilogue), TN with split-K over node chunks
+// (dZ^T * [x | 1]) -- the same GemmProblem contract as gemm.hip.
+#include "kernels.h"
+
+namespace hmp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BT = 128;      // tile edge
+constexpr int BKB = 32;      // K stage
+constexpr int BPITCH = 40;   // bf16 elements per row of a [row][k] image (80 bytes: 16-byte aligned rows)
+constexpr int BRPITCH = 136; // bf16 elements per k row of a [k][row] image (272 bytes: 8-byte aligned)
+constexpr int BLDS = BT * BPITCH > BKB * BRPITCH ? BT * BPITCH : BKB * BRPITCH;
+
+struct StageRegs {
+  float4 v[4];
+};
+
+// fast loader: the tile is interior in the vectorised direction and every row start is 16-byte aligned.
+//  kcontig: slot q covers row q / 8, k4 = (q % 8) * 4      rcontig: slot q covers k = q / 32, r4 = (q % 32) * 4
+__device__ __forceinline__ void bf_load_fast(StageRegs& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int k0, int kend) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * 256;
+    if (kcontig) {
+      const int r = q >> 3, k4 = (q & 7) * 4;
+      const int gr = r0 + r, gk = k0 + k4;
+      const bool rl = gr < R;
+      const int gkc = gk < kend ? gk : k0;
+      const float4 val = *reinterpret_cast<const float4*>(p + (int64_t)(rl ? gr : R - 1) * ld + gkc);
+      t.v[i] = make_float4(rl && gk + 0 < kend ? val.x : 0.f, rl && gk + 1 < kend ? val.y : 0.f, rl && gk + 2 < kend ? val.z : 0.f,
+                           rl && gk + 3 < kend ? val.w : 0.f);
+    } else {
+      const int k = q >> 5, r4 = (q & 31) * 4;
+      const int gk = k0 + k;
+      const bool kl = gk < kend;
+      const float4 val = *reinterpret_cast<const float4*>(p + (int64_t)(kl ? gk : k0) * ld + (r0 + r4));
+      t.v[i] = kl ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+// edge loader: element by element with bounds (last column tile, ones column, unaligned operands)
+__device__ __forceinline__ void bf_load_edge(StageRegs& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int n_real, int aug,
+                                             int k0, int kend) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * 256;
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kcontig) {
+      const int r = q >> 3, k4 = (q & 7) * 4;
+      const int gr = r0 + r;
+      if (gr < R) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + k4 + j < kend) e[j] = p[(int64_t)gr * ld + k0 + k4 + j];
+      }
+    } else {  // columns past n_real are zero, the ones column is virtual
+      const int k = q >> 5, r4 = (q & 31) * 4;
+      const int gk = k0 + k;
+      if (gk < kend) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = r0 + r4 + j;
+          e[j] = (c < n_real) ? p[(int64_t)gk * ld + c] : ((aug && c == n_real) ? 1.0f : 0.0f);
+        }
+      }
+    }
+    t.v[i] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+}
+
+__device__ __forceinline__ void bf_store(const StageRegs& t, __bf16* __restrict__ s, int kcontig) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * 256;
+    if (kcontig) {
+      const int r = q >> 3, k4 = (q & 7) * 4;
+      bf16x4 b;
+      b[0] = (__bf16)t.v[i].x; b[1] = (__bf16)t.v[i].y; b[2] = (__bf16)t.v[i].z; b[3] = (__bf16)t.v[i].w;
+      *reinterpret_cast<bf16x4*>(s + r * BPITCH + k4) = b;
+    } else {  // natural [k][row] image
+      const int k = q >> 5, r4 = (q & 31) * 4;
+      bf16x4 b;
+      b[0] = (__bf16)t.v[i].x; b[1] = (__bf16)t.v[i].y; b[2] = (__bf16)t.v[i].z; b[3] = (__bf16)t.v[i].w;
+      *reinterpret_cast<bf16x4*>(s + k * BRPITCH + r4) = b;
+    }
+  }
+}
+
+// MFMA operand (8 consecutive k of row `rowbase + lane % 32`, k half lane / 32) of k step ks
+//  [row][k] image: one 16-byte read.   [k][row] image: two hardware-transposed reads (ds_read_b64_tr_b16): inside a
+//  16-lane group, lane 4q+p supplies the address of k row q, columns 4p..4p+3 and receives column (lane % 16), 4 k rows.
+//  EXEC must be all ones here (no divergence in the main loop).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 bf_fetch(const __bf16* __restrict__ s, int kcontig, int rowbase, int ks, int lane) {
+  if (kcontig) return *reinterpret_cast<const bf16x8*>(s + (rowbase + (lane & 31)) * BPITCH + ks * 16 + 8 * (lane >> 5));
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int k0 = ks * 16 + 8 * (g >> 1);
+  const __bf16* a0 = s + (k0 + q) * BRPITCH + rowbase + 16 * (g & 1) + 4 * p;
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * BRPITCH));
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = lo;
+  u.h[1] = hi;
+  return u.v;
+}
+
+__device__ __forceinline__ float bf_act_mask(float h, int act, bool keep, float scale) {
+  if (!keep) return 0.f;
+  if (act == HMP_ACT_RELU) return h > 0.f ? scale : 0.f;
+  if (act == HMP_ACT_ELU) return h > 0.f ? scale : (h + scale);
+  return scale;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[BLDS];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[BLDS];
+  int pi = 0;
+  while (pi + 1 < gb.n && (int)blockIdx.x >= gb.p[pi + 1].tile_start) ++pi;
+  const GemmProblem& P = gb.p[pi];
+  const int local = blockIdx.x - P.tile_start;
+  // XCD-aware order as in gemm.hip: K chunk fastest; row tiles grouped by 8 so that the column tiles of a row tile share an L2
+  const int z = local % P.ksplit, t = local / P.ksplit;
+  const int grp = t / (8 * P.tiles_n), within = t % (8 * P.tiles_n);
+  const int rows_in_grp = min(8, P.tiles_m - grp * 8);
+  const int m0 = (grp * 8 + within % rows_in_grp) * BT, n0 = (within / rows_in_grp) * BT;
+  const int kbeg = z * P.kchunk;
+  const int kend = min(P.K, kbeg + P.kchunk);
+  const int a_kc = P.trans_a ? 0 : 1;
+  const int b_kc = P.trans_b ? 1 : 0;
+  // block-uniform loader choice
+  const bool a_al = (P.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(P.A) & 15) == 0;
+  const bool b_al = (P.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(P.B) & 15) == 0;
+  const bool a_fast = a_al && (a_kc || m0 + BT <= P.M);
+  const bool b_fast = b_al && (b_kc || n0 + BT <= P.n_real);
+  // virtual ones column of B (bias gradient = column sums of A over k): instead of a whole extra column tile for ONE column
+  // (a third of the config-5 weight-gradient work), the first column tile's wn == 0 waves run one more MFMA per row tile
+  // and k step against an all-ones operand; column 0 of that product is the column sum.
+  const bool ones_here = P.aug_ones && n0 == 0 && (threadIdx.x >> 7) == 0;  // wave-uniform
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x16 acc1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+  StageRegs ra, rb;
+  auto load = [&](int k0) {
+    if (a_fast) bf_load_fast(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
+    else bf_load_edge(ra, P.A, P.lda, a_kc, m0, P.M, P.M, 0, k0, kend);
+    if (b_fast) bf_load_fast(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
+    else bf_load_edge(rb, P.B, P.ldb, b_kc, n0, P.n_real, P.n_real, P.aug_ones, k0, kend);
+  };
+  load(kbeg);
+  for (int kt = kbeg; kt < kend; kt += BKB) {
+    bf_store(ra, As, a_kc);
+    bf_store(rb, Bs, b_kc);
+    __syncthreads();
+    if (kt + BKB < kend) load(kt + BKB);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = bf_fetch(As, a_kc, wm * 64 + i * 32, ks, lane);
+        bv[i] = bf_fetch(Bs, b_kc, wn * 64 + i * 32, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      if (ones_here) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], ones, acc1[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* C = P.C + (int64_t)z * P.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= P.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= P.M) continue;
+        float v = acc[i][j][r];
+        if (P.epi == EPI_ACTMASK) {
+          const float h = P.H[(int64_t)row * P.ldh + col];
+          const bool keep = !P.drop_on || (__float_as_uint(h) != 0x80000000u);  // dropped elements were stored as -0.0f
+          v *= bf_act_mask(h, P.act, keep, P.drop_on ? P.drop.scale : 1.f);
+        }
+        C[(int64_t)row * P.ldc + col] = v;
+      }
+    }
+  if (ones_here && (lane & 31) == 0) {  // column 0 of the ones product -> C[:, n_real]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < P.M) C[(int64_t)row * P.ldc + P.n_real] = acc1[i][r];
+      }
+  }
+}
+
+int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
+  HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
+  int start = 0, all_tiles = 0;
+  for (int i = 0; i < gb.n; ++i) all_tiles += cdiv(gb.p[i].M, BT) * cdiv(gb.p[i].aug_ones ? (gb.p[i].n_real > 0 ? gb.p[i].n_real : 1) : gb.p[i].N, BT);
+  for (int i = 0; i < gb.n; ++i) {
+    GemmProblem& p = gb.p[i];
+    HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_bf16: negative size");
+    p.tiles_m = cdiv(p.M, BT);
+    p.tiles_n = cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, BT);  // the ones column rides in the first column tile
+    const int tiles = p.tiles_m * p.tiles_n;
+    int ks = 1;
+    if (want_split && tiles > 0) {
+      ks = 1024 / (all_tiles > 0 ? all_tiles : 1);  // aim at ~1024 workgroups over the launch
+      const int max_by_k = cdiv(p.K, BKB);
+      if (ks > max_by_k) ks = max_by_k;
+      if (ks > max_slabs) ks = max_slabs;
+      if (ks < 1) ks = 1;
+    }
+    int kchunk = cdiv(cdiv(p.K, ks), BKB) * BKB;
+    if (kchunk < BKB) kchunk = BKB;
+    ks = p.K > 0 ? cdiv(p.K, kchunk) : 1;
+    p.ksplit = ks;
+    p.kchunk = kchunk;
+    p.tile_start = start;
+    start += tiles * ks;
+  }
+  gb.total_tiles = start;
+  if (start == 0) return HMP_OK;
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(start), dim3(256), 0, st, gb);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
+}  // namespace hmp
+
+extern "C" int hmp_gemm_bf16(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b,
+                             float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(d_a && d_b && d_c, "hmp_gemm_bf16: null pointer");
+  HMP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "hmp_gemm_bf16: negative size");
+  HMP_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "hmp_gemm_bf16: leading dimension too small");
+  GemmBatch gb;
+  memset(&gb, 0, sizeof(gb));
+  gb.n = 1;
+  GemmProblem& p = gb.p[0];
+  p.A = d_a; p.B = d_b; p.C = d_c;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.trans_a = trans_a; p.trans_b = trans_b;
+  p.n_real = N;
+  p.epi = EPI_NONE;
+  if (M == 0 || N == 0) return HMP_OK;
+  return gemm_bf16_launch(gb, false, 1, (hipStream_t)stream);
+}

@@ -37,6 +37,8 @@ struct GemmBatch {
 
 // chooses tile shape + split-K (only when want_split: C is then a stack of slabs) and launches
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
+// same contract on the bf16 matrix pipe (operands rounded to bf16 on their way into LDS, fp32 accumulate): gemm_bf16.hip
+int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // front kernel of the small-batch step (front.hip): layer-0 projection tiles + plan parts + pack blocks in one launch

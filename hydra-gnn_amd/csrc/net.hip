@@ -55,7 +55,8 @@ struct LayerLayout {
   GatLayerS h_gat;
 };
 
-constexpr int MAX_SLABS = 16;
+constexpr int MAX_SLABS = 64;        // split-K slabs per weight-gradient problem (large batches use them all)
+constexpr int TN_DIRECT_SLABS = 16;  // small batches: more slabs only lengthen the gradient un-pack
 
 struct ProfRec {
   int cls;
@@ -126,6 +127,7 @@ struct hmp_net {
   int branch_mask = 0;     // HMP_BRANCH bits: 1 = pack + layer-0 projection next to the plan, 2 = weight gradients next to the backward chain
   bool dw_branch = false;  // weight-gradient GEMMs per layer on a side stream instead of one merged launch
   int dw_mode = -1;        // HMP_DW_BRANCH override (0 / 1), -1 = automatic
+  int compute_bf16 = 0;    // hmp_net_set_compute: large grouped GEMMs on the bf16 matrix pipe (fp32 storage and accumulation)
   int fuse_mode = -1;      // HMP_FUSE override (0 / 1), -1 = automatic: row-local GEMMs ride in the aggregation kernels
   bool fuse_now = false;   // decision for the current batch
   // fused training step: labels for the cross entropy riding in the last aggregation, Adam riding in the gradient un-pack
@@ -732,13 +734,22 @@ const float* h_ptr(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? 
 int h_ld(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.ldx[t] : n->ld[l][t]; }
 
 // launches a list of GEMM problems in groups of GEMM_MAX_PROB; ksplit_out receives the split of each problem
-int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out) {
+int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out, bool allow_bf16 = false) {
+  // bf16 compute mode: only the throughput-bound regime (>= 1024 64x64 tiles in the call) leaves the exact fp32 kernel
+  int64_t tiles64 = 0;
+  double work = 0.0;
+  for (const GemmProblem& p : ps) {
+    tiles64 += (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
+    work += (double)p.M * p.N * p.K;
+  }
+  const bool bf16 = allow_bf16 && (tiles64 >= 1024 || work >= 1e9);
   for (size_t base = 0; base < ps.size(); base += GEMM_MAX_PROB) {
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     const size_t cnt = (ps.size() - base) < (size_t)GEMM_MAX_PROB ? (ps.size() - base) : (size_t)GEMM_MAX_PROB;
     for (size_t i = 0; i < cnt; ++i) gb.p[gb.n++] = ps[base + i];
-    HMP_TRY(gemm_launch(gb, want_split, MAX_SLABS, st));
+    if (bf16) HMP_TRY(gemm_bf16_launch(gb, want_split, MAX_SLABS, st));
+    else HMP_TRY(gemm_launch(gb, want_split, MAX_SLABS, st));
     if (ksplit_out)
       for (size_t i = 0; i < cnt; ++i) ksplit_out->push_back(gb.p[i].ksplit);
   }
@@ -870,7 +881,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         p.epi = EPI_NONE;
         ps.push_back(p);
       }
-      HMP_TRY(gemm_many(ps, false, st, nullptr));
+      HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
     }
     z_done = false;
     if (l == 0 && !front) {
@@ -1098,7 +1109,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         }
         ps.push_back(p);
       }
-      HMP_TRY(gemm_many(ps, false, st, nullptr));
+      HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
     }
     {  // weight + bias gradient: dWp = dZ^T * [H | 1], split over node chunks (+ GAT: bias column sums, d V_edge)
       std::vector<GemmProblem> local_ps;
@@ -1155,7 +1166,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       if (n->dw_branch) {
         Scope sc(n, KC_GEMM_BWD, wst);
         std::vector<int> ks;
-        HMP_TRY(gemm_many(ps, true, wst, &ks));
+        HMP_TRY(gemm_many(ps, true, wst, &ks, n->compute_bf16 != 0));
         for (size_t i = 0; i < ids.size(); ++i) n->dyn.n_slabs[ids[i]] = (unsigned char)ks[i];
       }
     }
@@ -1170,7 +1181,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       const char* tv = getenv("HMP_TN");  // 0: LDS-staged split-K kernel (tests)
       if (tv && tv[0] == '0') direct = false;
       for (size_t i = 0; i < wps.size() && direct; ++i)
-        if (wps[i].K > MAX_SLABS * 384) direct = false;
+        if (wps[i].K > TN_DIRECT_SLABS * 384) direct = false;
       for (size_t base = 0; base < wps.size() && direct; base += GEMM_MAX_PROB) {
         TnBatch tb;
         memset(&tb, 0, sizeof(tb));
@@ -1183,12 +1194,12 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           P.n_real = g.n_real; P.aug_ones = g.aug_ones;
         }
         int ok = 0;
-        HMP_TRY(gemm_tn_direct_launch(tb, MAX_SLABS, &ok, st));
+        HMP_TRY(gemm_tn_direct_launch(tb, TN_DIRECT_SLABS, &ok, st));
         HMP_CHECK_ARG(ok, "net: weight-gradient problem too deep for the direct kernel after the size check");
         for (size_t i = 0; i < cnt; ++i) ks.push_back(tb.p[i].ksplit);
       }
     }
-    if (!direct) HMP_TRY(gemm_many(wps, true, st, &ks));
+    if (!direct) HMP_TRY(gemm_many(wps, true, st, &ks, n->compute_bf16 != 0));
     for (size_t i = 0; i < wids.size(); ++i) n->dyn.n_slabs[wids[i]] = (unsigned char)ks[i];
   }
   {
@@ -1356,6 +1367,13 @@ extern "C" int hmp_net_read_state(hmp_net* n, int32_t* step, int32_t* status, vo
   HMP_HIP(hipMemcpy(&h, n->d_state, sizeof(h), hipMemcpyDeviceToHost));
   if (step) *step = h.step;
   if (status) *status = h.status;
+  return HMP_OK;
+}
+
+extern "C" int hmp_net_set_compute(hmp_net* n, int32_t bf16) {
+  HMP_CHECK_ARG(n, "hmp_net_set_compute: null net");
+  HMP_CHECK_ARG(bf16 == 0 || bf16 == 1, "hmp_net_set_compute: mode %d (0 = fp32, 1 = bf16 MFMA for large GEMMs)", bf16);
+  n->compute_bf16 = bf16;
   return HMP_OK;
 }
 

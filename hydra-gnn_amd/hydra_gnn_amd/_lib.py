@@ -104,6 +104,8 @@ SIGNATURES = {
     "hmp_segment_mean_fwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
     "hmp_segment_mean_bwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
     "hmp_gemm_f32": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "hmp_gemm_bf16": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "hmp_net_set_compute": (C.c_int, [_VP, _I32]),
     "hmp_gat_fwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _VP, Plan, GatArgs, _VP, _VP, _VP, _I32, _VP]),
     "hmp_gat_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _I32, _VP, _VP, Plan, GatArgs, _VP, _VP, _VP, _VP, _VP,
                               _VP, _I32, _VP, _I32, _VP, _I32, _VP]),

@@ -89,6 +89,17 @@ class NativeNet:
         self._flat: Optional[torch.Tensor] = None
         self._lib = None
         self._fwd_token = 0
+        self._compute_bf16 = False
+
+    def set_compute(self, precision: str) -> None:
+        """'fp32' (default): every projection on the exact fp32 MFMA path.  'bf16': GEMM calls in the throughput-bound regime
+        (>= 1024 64x64 output tiles, i.e. BASELINE config 5) round their operands to bf16 and accumulate in fp32; storage stays
+        fp32.  An explicit precision choice: outside the 1e-5 parity bar of the fp32 path."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._compute_bf16 = precision == "bf16"
+        if self._handle is not None:
+            _lib.check(self._lib.hmp_net_set_compute(self._handle, int(self._compute_bf16)))
 
     # ---- static analysis ---------------------------------------------------------------------
     def _mark_liveness(self) -> None:
@@ -191,6 +202,8 @@ class NativeNet:
             sp = self._spec()
             _lib.check(self._lib.hmp_net_create(C.byref(sp), C.byref(h)))
             self._handle = h
+            if self._compute_bf16:
+                _lib.check(self._lib.hmp_net_set_compute(h, 1))
         return self._handle
 
     def __del__(self):

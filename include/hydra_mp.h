@@ -88,6 +88,9 @@ int hmp_segment_mean_bwd(const float* d_gout, int32_t ldg, int32_t F, hmp_plan p
  *    C[M,N] = op(A)[M,K] * op(B)[K,N];  trans_a: A stored [K][M];  trans_b: B stored [N][K]
  *    (trans_b = 1 is nn.Linear's weight layout).
  * ------------------------------------------------------------------------------------------- */
+/* same problem on the bf16 matrix pipe (operands rounded to bf16, fp32 accumulate); unit-test entry of gemm_bf16.hip */
+int hmp_gemm_bf16(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b, float* d_c,
+                  int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 int hmp_gemm_f32(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b,
                  float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 
@@ -250,6 +253,10 @@ int hmp_net_step_adam(hmp_net* net, float* d_params, const float* d_grads, float
  * gradient un-pack kernel where the network allows it (SAGE stacks); the result equals A followed by B. */
 int hmp_net_step_fused(hmp_net* net, const hmp_batch* batch, float* d_params, float* d_grads, float* d_m, float* d_v,
                        const hmp_train_args* args, void* stream);
+/* compute mode of the dense projections: 0 (default) exact fp32 MFMA everywhere; 1 = GEMM calls in the throughput-bound regime
+ * (>= 1024 64x64 output tiles: BASELINE config 5) round their fp32 operands to bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation.  Storage stays fp32.  Not within the 1e-5 parity bar: an explicit precision choice of the caller. */
+int hmp_net_set_compute(hmp_net* net, int32_t bf16);
 /* host copy of {step counter, status bits}; synchronises the stream */
 int hmp_net_read_state(hmp_net* net, int32_t* step, int32_t* status, void* stream);
 

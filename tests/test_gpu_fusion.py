@@ -224,3 +224,37 @@ def test_front_kernel_odd_shapes():
     for name, p in o64.named_parameters():
         if p.grad is not None:
             torch.testing.assert_close(grads[name].cpu().double(), p.grad, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
+
+
+def test_bf16_compute_mode_on_a_large_graph():
+    """precision='bf16' only touches GEMM calls with >= 1024 64x64 tiles: a 24k-object graph with hidden 256 takes the bf16 path for
+    its projections; logits and loss stay within bf16 rounding of the fp32 engine, the fp32 mode is unchanged, small batches are
+    bit-identical in both modes."""
+    kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, dropout=0.0)
+    g = workloads.big_hetero_graph(n_obj=24000, n_rooms=240, seed=3).to(DEV)
+    _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+    net.eval()
+    y = g["rooms"].y
+
+    def fwd_bwd():
+        for p in net.parameters():
+            p.grad = None
+        pred = net(g)
+        net.loss(pred, y, y != 25).backward()
+        return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    ref, gref = fwd_bwd()
+    net.native().set_compute("bf16")
+    out, gout = fwd_bwd()
+    assert not torch.equal(out, ref)  # the bf16 path really ran
+    rel = float((out - ref).abs().max() / ref.abs().max())
+    assert rel < 2e-2, rel
+    for k, gr in gref.items():  # weights, root weights and biases (the ones-column path of the bf16 weight-gradient GEMM)
+        err = float((gout[k] - gr).abs().max() / (gr.abs().max() + 1e-12))
+        assert err < 5e-2, (k, err)
+    small = workloads.config2_batch(2)
+    _, net2 = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+    net2.eval()
+    a = net2(small.to(DEV)).detach().clone()
+    net2.native().set_compute("bf16")
+    assert torch.equal(net2(small.to(DEV)), a)

@@ -237,3 +237,21 @@ def test_dropout_mask_rate_and_determinism():
     assert not torch.equal(a, c)
     keep = float(a.float().mean())
     assert abs(keep - 0.75) < 0.005
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(256, 256, 64, 0, 1), (1000, 300, 257, 0, 1), (513, 768, 256, 0, 0), (300, 257, 5000, 1, 0),
+                                         (128, 128, 32, 1, 1), (77, 130, 33, 0, 1)])
+def test_gemm_bf16_matches_bf16_rounded_inputs(M, N, K, ta, tb):
+    """hmp_gemm_bf16 = fp32-accumulated product of the bf16-ROUNDED operands (round to nearest even): compared with exactly that
+    in float64 (tolerance = fp32 accumulation of K terms), for every operand layout and ragged sizes (edge loaders)."""
+    lib = _lib.require_device()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    a, b = A.to(dev()), B.to(dev())
+    c = torch.empty(M, N, device=dev())
+    _lib.check(lib.hmp_gemm_bf16(a.data_ptr(), a.stride(0), ta, b.data_ptr(), b.stride(0), tb, c.data_ptr(), N, M, N, K, _lib.stream_ptr()))
+    Ar = A.bfloat16().double()
+    Br = B.bfloat16().double()
+    ref = (Ar.t() if ta else Ar) @ (Br.t() if tb else Br)
+    torch.testing.assert_close(c.cpu().double(), ref, atol=2e-4 * (K ** 0.5) / 16 + 1e-5, rtol=2e-5)
