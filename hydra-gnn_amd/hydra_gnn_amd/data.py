@@ -249,6 +249,75 @@ def collate(graphs: Sequence[HeteroData]) -> HeteroData:
     return out
 
 
+# reference: heterogeneous_data_to_homogeneous / heterogeneous_htree_to_homogeneous, src/hydra_gnn/mp3d_dataset.py:29-119
+# ([PyG] HeteroData.to_homogeneous: node types concatenated in store order, every edge type's edge_index shifted by the
+# offsets of its endpoint types and concatenated in edge-type order; node_type / edge_type id vectors).
+def heterogeneous_data_to_homogeneous(torch_data: HeteroData):
+    """-> (Data with x, edge_index, node_type, edge_type [, y, edge_attr], list of node type names).  Features are
+    zero-padded to the widest node type (reference :36-51)."""
+    node_types = [t for t in torch_data.node_types if "x" in torch_data[t]]
+    width = max(torch_data[t].num_node_features for t in node_types)
+    xs, ys, nts, off = [], [], [], {}
+    n = 0
+    has_y = all("y" in torch_data[t] for t in node_types)
+    for i, t in enumerate(node_types):
+        x = torch_data[t].x
+        if x.size(0) == 0:
+            x = torch.empty((0, width), dtype=x.dtype)
+        xs.append(torch.nn.functional.pad(x, (0, width - x.size(1), 0, 0), mode="constant", value=0))
+        nts.append(torch.full((x.size(0),), i, dtype=torch.int64))
+        if has_y:
+            ys.append(torch_data[t].y)
+        off[t] = n
+        n += x.size(0)
+    eis, ets, eas = [], [], []
+    edge_types = [e for e in torch_data.edge_types if "edge_index" in torch_data[e]]
+    has_ea = len(edge_types) > 0 and all("edge_attr" in torch_data[e] for e in edge_types)
+    for i, e in enumerate(edge_types):
+        ei = torch_data[e].edge_index
+        shift = torch.tensor([[off[e[0]]], [off[e[2]]]], dtype=ei.dtype)
+        eis.append(ei + shift)
+        ets.append(torch.full((ei.size(1),), i, dtype=torch.int64))
+        if has_ea:
+            eas.append(torch_data[e].edge_attr)
+    out = Data(x=torch.cat(xs, 0), node_type=torch.cat(nts, 0),
+               edge_index=torch.cat(eis, 1) if eis else torch.empty((2, 0), dtype=torch.int64),
+               edge_type=torch.cat(ets, 0) if ets else torch.empty((0,), dtype=torch.int64))
+    if has_y:
+        out.y = torch.cat(ys, 0)
+    if has_ea:
+        out.edge_attr = torch.cat(eas, 0)
+    return out, node_types
+
+
+def heterogeneous_htree_to_homogeneous(torch_data: HeteroData) -> Data:
+    """Augmented H-tree as one homogeneous graph (reference :73-119): ``edge_index`` keeps the H-tree edges,
+    ``init_edge_index`` the virtual -> clique edges, ``pool_edge_index`` the leaf -> virtual edges; ``room_mask`` /
+    ``object_mask`` mark the virtual nodes (the classification nodes)."""
+    assert "object_virtual" in torch_data.x_dict and "room_virtual" in torch_data.x_dict
+    if "y" in torch_data["room_virtual"]:
+        y_dtype = torch_data["room_virtual"].y.dtype
+        for t in torch_data.x_dict:
+            if "y" not in torch_data[t]:
+                torch_data[t].y = -torch.ones(torch_data[t].num_nodes, dtype=y_dtype)
+    d, node_types = heterogeneous_data_to_homogeneous(torch_data)
+    ov, rv = node_types.index("object_virtual"), node_types.index("room_virtual")
+    src_t = d.node_type[d.edge_index[0]]
+    dst_t = d.node_type[d.edge_index[1]]
+    init_mask = (src_t == ov) | (src_t == rv)
+    pool_mask = (dst_t == ov) | (dst_t == rv)
+    d.init_edge_index = d.edge_index[:, init_mask]
+    d.pool_edge_index = d.edge_index[:, pool_mask]
+    keep = ~(init_mask | pool_mask)
+    d.edge_index = d.edge_index[:, keep]
+    d.edge_type = d.edge_type[keep]
+    if hasattr(d, "edge_attr"):
+        d.edge_attr = d.edge_attr[keep, :]
+    d.room_mask = d.node_type == rv
+    d.object_mask = d.node_type == ov
+    return d
+
+
 def collate_homogeneous(graphs: Sequence[Data]) -> Data:
     assert len(graphs) > 0
     out = Data()

@@ -390,8 +390,10 @@ class TrainStep:
 
     def __init__(self, net: NativeNet, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignored_label: int = 25, seed: int = 0, training: bool = True, use_graph: bool = True,
-                 process_group=None, force_collective: bool = False):
+                 process_group=None, force_collective: bool = False, view=None):
         self.net = net
+        # homogeneous models: callable that presents their `Data` through the hetero accessors the executor reads
+        self.view = view
         # run the data-parallel launch structure (two graphs around one all-reduce) even with a single rank
         self.force_collective = bool(force_collective)
         self.args = _lib.TrainArgs(lr, betas[0], betas[1], eps, weight_decay, ignored_label, seed, int(training))
@@ -442,7 +444,7 @@ class TrainStep:
         net = self.net
         if net.flat_params() is not self.flat:
             raise _lib.HydraMPError("model parameters were moved after TrainStep was created")
-        h = net.make_batch(data, labels)
+        h = net.make_batch(self.view(data) if self.view is not None else data, labels)
         dev = self.flat.device
         with torch.cuda.device(dev):
             net._ensure_workspace(h, dev)

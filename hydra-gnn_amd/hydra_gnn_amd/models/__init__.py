@@ -2,5 +2,6 @@
 from .heterogeneous_network import HeterogeneousNetwork
 from .heterogeneous_neural_tree_network import HeterogeneousNeuralTreeNetwork, LeafPool
 from .homogeneous_network import HomogeneousNetwork
+from .homogeneous_neural_tree_network import HomogeneousNeuralTreeNetwork
 
-__all__ = ["HeterogeneousNetwork", "HeterogeneousNeuralTreeNetwork", "HomogeneousNetwork", "LeafPool"]
+__all__ = ["HeterogeneousNetwork", "HeterogeneousNeuralTreeNetwork", "HomogeneousNetwork", "HomogeneousNeuralTreeNetwork", "LeafPool"]

@@ -41,7 +41,7 @@ class _NativeModule(nn.Module):
         """Fused native training step (fwd + masked CE + bwd [+ all-reduce] + Adam), see engine.TrainStep."""
         from ..engine import TrainStep
 
-        return TrainStep(self.native(), lr=lr, weight_decay=weight_decay, **kw)
+        return TrainStep(self.native(), lr=lr, weight_decay=weight_decay, view=getattr(self, "_view", None), **kw)
 
     def loss(self, pred, label, mask=None):
         return cross_entropy_loss(pred, label, mask)

@@ -87,6 +87,9 @@ class HomogeneousNetwork(_NativeModule):
             layers.append(LayerDesc([cd], {_NODE: width}, act, 0.0 if last else self.dropout))
         return NativeNet([_NODE], {_NODE: self.input_dim}, [_EDGE], layers, readout=_NODE)
 
+    def _view(self, data):
+        return _HomoView(data)
+
     def forward(self, data):
         out = self._run(_HomoView(data))
         out = out[:, : self.native().layers[-1].out_dims[_NODE]]

@@ -6,6 +6,7 @@ Follows, without importing it (it needs torch_geometric):
 * ``src/hydra_gnn/models/heterogeneous_network.py:40-136``  -> :class:`HeterogeneousNetwork`
 * ``src/hydra_gnn/models/heterogeneous_neural_tree_network.py:40-205`` -> :class:`HeterogeneousNeuralTreeNetwork`
 * ``src/hydra_gnn/models/homogeneous_network.py:44-147`` (SAGE / GAT branches) -> :class:`HomogeneousNetwork`
+* ``src/hydra_gnn/models/homogeneous_neural_tree_network.py:7-109`` -> :class:`HomogeneousNeuralTreeNetwork`
 * ``src/hydra_gnn/models/utils.py:9-140`` (layer builders)
 
 state_dict keys equal the reference's PyG <= 2.3 keys, so a state_dict moves
@@ -276,3 +277,32 @@ class HomogeneousNetwork(nn.Module):
 
     def loss(self, pred, label, mask=None):
         return cross_entropy_loss(pred, label, mask)
+
+
+class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
+    """homogeneous_neural_tree_network.py:7-109 (SAGE / GAT / GAT_edge branches): ``pre_mp`` GAT over ``init_edge_index`` applied
+    to EVERY node (:83-84), the parent's convs over ``edge_index``, ``LeafPool`` over ``pool_edge_index`` (:96), ``x[room_mask]``."""
+
+    def __init__(self, input_dim, output_dim=None, output_dim_dict=None, conv_block="GraphSAGE", disable_initialization=False,
+                 hidden_dim=None, num_layers=None, GAT_hidden_dims=None, GAT_heads=None, GAT_concats=None, dropout=0.25,
+                 dropout_fn=default_dropout, **kwargs):
+        super().__init__(input_dim, output_dim, output_dim_dict, conv_block, hidden_dim, num_layers, GAT_hidden_dims, GAT_heads,
+                         GAT_concats, dropout, dropout_fn=dropout_fn, **kwargs)
+        assert self.classification_task == "room"
+        self.pre_mp = None if disable_initialization else GATConv(input_dim, input_dim, heads=1, concat=False, dropout=0.0,
+                                                                  add_self_loops=False)
+        self.post_mp_pool = LeafPool()
+
+    def forward(self, data):
+        x, edge_index = data.x, data.edge_index
+        if self.pre_mp is not None:
+            x = self.pre_mp(x, data.init_edge_index)
+        for l in range(self.num_layers):
+            if self.conv_block == "GAT_edge":
+                x = self.convs[l](x, edge_index, data.edge_attr)
+            else:
+                x = self.convs[l](x, edge_index)
+            if l != self.num_layers - 1:
+                x = self._act_drop(x, l)
+        x = self.post_mp_pool(x, data.pool_edge_index)
+        return x[data.room_mask, :]
