@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
                     help="compute mode of the large GEMMs (default: bf16 for config 5 as BASELINE.json names it, fp32 otherwise)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="1 GPU only: run the data-parallel launch structure (un-pack, RCCL all-reduce in a 1-rank group, Adam) "
+                         "to price the collective path without a second GPU; diagnosis, not the bench line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -219,6 +222,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+    elif args.force_collective:
+        import socket
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     import hydra_gnn_amd.models as hmodels
     from hydra_gnn_amd import _lib
@@ -231,7 +242,8 @@ def main():
     batch = batch_cpu.to(dev)
     labels = batch[label_type].y
     step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=20250225, use_graph=args.graph,
-                          process_group=True if world > 1 else None)
+                          process_group=True if (world > 1 or args.force_collective) else None,
+                          force_collective=args.force_collective)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -418,6 +430,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

@@ -125,3 +125,61 @@ def test_htree_fixture_is_consistent():
     assert batch["room_virtual"].num_nodes == batch["room_virtual"].y.numel()
     pool = batch["room", "r_to_rv", "room_virtual"].edge_index
     assert int(pool[1].max()) < batch["room_virtual"].num_nodes and pool.shape[1] == batch["room"].num_nodes
+
+
+def test_hetero_htree_to_homogeneous_follows_the_reference_layout():
+    """heterogeneous_htree_to_homogeneous (reference mp3d_dataset.py:73-119): node types concatenated in store order with
+    zero-padded features, init edges = edges leaving a virtual node, pool edges = edges entering one, the rest (the H-tree
+    itself) stays in edge_index and is undirected; room_mask / object_mask mark the virtual nodes; y = -1 elsewhere."""
+    from hydra_gnn_amd.data import heterogeneous_htree_to_homogeneous
+
+    npz = np.load(workloads.HTREE_FIXTURE)
+    g = workloads.htree_graph(npz, 0, np.random.Generator(np.random.PCG64(3)))
+    counts = {t: g[t].num_nodes for t in g.node_types}
+    n_init = sum(g[e].num_edges for e in g.edge_types if e[0] in ("object_virtual", "room_virtual"))
+    n_pool = sum(g[e].num_edges for e in g.edge_types if e[2] in ("object_virtual", "room_virtual"))
+    n_tree = sum(g[e].num_edges for e in HTREE_EDGE_TYPES)
+    y_rv = g["room_virtual"].y.clone()
+    d = heterogeneous_htree_to_homogeneous(g)
+    assert d.x.shape == (sum(counts.values()), 306)
+    assert d.init_edge_index.shape[1] == n_init and d.pool_edge_index.shape[1] == n_pool and d.edge_index.shape[1] == n_tree
+    assert int(d.room_mask.sum()) == counts["room_virtual"] and int(d.object_mask.sum()) == counts["object_virtual"]
+    assert torch.equal(d.y[d.room_mask], y_rv) and bool((d.y[~d.room_mask] == -1).all())
+    # 6-d node types are zero padded to 306
+    order = [t for t in g.node_types]
+    off = np.cumsum([0] + [counts[t] for t in order])
+    i_room = order.index("room")
+    assert bool((d.x[off[i_room]:off[i_room + 1], 6:] == 0).all())
+    # the H-tree part is undirected: every edge has its reverse
+    fwd = set(map(tuple, d.edge_index.t().tolist()))
+    assert all((b, a) in fwd for a, b in fwd)
+    # init edges start at virtual nodes, pool edges end there
+    virt = d.room_mask | d.object_mask
+    assert bool(virt[d.init_edge_index[0]].all()) and bool(virt[d.pool_edge_index[1]].all())
+
+
+def test_oracle_homogeneous_htree_network_matches_its_definition():
+    """oracle HomogeneousNeuralTreeNetwork = pre_mp GAT on init edges (every node) -> convs on edge_index -> LeafPool mean over
+    pool edges -> rows of room_mask (reference homogeneous_neural_tree_network.py:75-103), checked against a hand-rolled
+    composition of the oracle operators"""
+    from hydra_gnn_amd.data import collate_homogeneous, heterogeneous_htree_to_homogeneous
+    from oracle import models as omodels
+    from oracle.pyg_ref import LeafPool
+
+    npz = np.load(workloads.HTREE_FIXTURE)
+    rng = np.random.Generator(np.random.PCG64(4))
+    gs = []
+    for i in range(2):
+        d = heterogeneous_htree_to_homogeneous(workloads.htree_graph(npz, i, rng))
+        del d.__dict__["edge_type"]
+        d.x = d.x[:, :6].contiguous()
+        gs.append(d)
+    b = collate_homogeneous(gs)
+    torch.manual_seed(0)
+    m = omodels.HomogeneousNeuralTreeNetwork(6, output_dim=26, conv_block="GraphSAGE", hidden_dim=8, num_layers=2, dropout=0.0).eval()
+    x = m.pre_mp(b.x, b.init_edge_index)
+    x = torch.relu(m.convs[0](x, b.edge_index))
+    x = m.convs[1](x, b.edge_index)
+    x = LeafPool()(x, b.pool_edge_index)
+    torch.testing.assert_close(m(b), x[b.room_mask])
+    assert set(m.state_dict()) >= {"pre_mp.att_src", "pre_mp.att_dst", "pre_mp.lin_src.weight", "pre_mp.bias", "convs.0.lin_l.weight"}
