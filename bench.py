@@ -257,6 +257,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(batch, labels)
+    t_issue = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind; not a second measurement)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -295,6 +296,7 @@ def main():
             "launch": "eager, one stream" if not args.graph else ("hipGraph replay, 1 graph/step" if world == 1 else
                                                                    "hipGraph replay, 2 graphs/step around the all-reduce"),
             "final_loss": round(final_loss, 5),
+            "host_issue_us_per_step": round(1e6 * t_issue / args.steps, 1),
         },
     }
 

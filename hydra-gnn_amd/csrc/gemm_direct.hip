@@ -40,6 +40,8 @@ __device__ __forceinline__ void reduce4(f32x16& acc, float* red /* [4][16][64] *
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TN_MAXI = 24;  // 2-k MFMA steps per wave and trip: a block covers 4 * 24 * 2 = 192 nodes per trip
 
+// (A 32x64 tile with two accumulators per wave -- A fetched once per 64 output columns -- was measured SLOWER: 28.8 us
+// against 13.0 us for the config-2 weight gradients; 72 loads per lane and trip, 2 blocks per CU.)
 __global__ __launch_bounds__(256, 2) void gemm_tn_direct_kernel(const TnBatch tb) {
   __shared__ float red[4 * 16 * 64];
   const int blk = blockIdx.x;

@@ -1,0 +1,147 @@
+"""Device-resident dataset + device-side collation.
+
+The reference feeds the training loop through PyG's ``DataLoader`` (``base_training_job.py:164-178``): every step it
+collates ``batch_size`` ``HeteroData`` objects on the host (``Batch.from_data_list``) and copies the result to the device
+(``batch.to(device)``, :205).  With the native step at ~0.1 ms that host work dominates.  :class:`GraphStore` uploads the
+whole list of graphs ONCE as packed per-type arrays (MP3D: 90 scenes x 5 trajectories of 10^2-node graphs -- a few hundred
+MB) and :meth:`GraphStore.collate` assembles a batch with the gather kernels of ``csrc/collate.hip``
+(``hmp_collate_rows`` / ``hmp_collate_edges``).  The host only computes the ``[B + 1]`` offset vectors of the batch (numpy
+cumsums over per-graph counts it keeps) and ships them in ONE small pinned H2D copy.
+
+The result is a :class:`hydra_gnn_amd.data.HeteroData` on the device with the same content, order and dtypes as
+``data.collate(graphs).to(device)`` (bit-identical: ``tests/test_gpu_collate.py``), incl. ``batch`` / ``ptr`` vectors and
+``num_graphs``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import EdgeType, HeteroData
+
+
+class _Packed:
+    """all graphs' rows of one attribute back to back + [G + 1] row offsets (host copy kept for the offset arithmetic)"""
+
+    def __init__(self, parts: List[torch.Tensor], device):
+        self.counts = np.array([int(p.size(0)) for p in parts], dtype=np.int64)
+        self.ptr_host = np.concatenate([[0], np.cumsum(self.counts)]).astype(np.int64)
+        self.data = torch.cat(parts, dim=0).contiguous().to(device)
+        self.ptr = torch.from_numpy(self.ptr_host).to(device)
+        self.row_shape = tuple(self.data.shape[1:])
+        self.row_bytes = int(self.data.element_size()) * (int(np.prod(self.row_shape, dtype=np.int64)) if self.row_shape else 1)
+        if self.row_bytes % 4 != 0:
+            raise _lib.HydraMPError(f"attribute rows of {self.row_bytes} bytes: the collate kernels move 4-byte units "
+                                    "(store bool / int8 masks as int32)")
+
+
+class GraphStore:
+    def __init__(self, graphs: Sequence[HeteroData], device="cuda:0"):
+        assert len(graphs) > 0
+        self.device = torch.device(device)
+        self.lib = _lib.require_device()
+        self.n_graphs = len(graphs)
+        g0 = graphs[0]
+        self.node_types = list(g0.node_types)
+        self.edge_types: List[EdgeType] = list(g0.edge_types)
+        # node attributes (tensors whose first dimension is the node count)
+        self.node_attrs: Dict[str, Dict[str, _Packed]] = {}
+        self.node_counts: Dict[str, np.ndarray] = {}
+        self.count_only: Dict[str, bool] = {}
+        for t in self.node_types:
+            keys = [k for k in g0[t].keys() if isinstance(getattr(g0[t], k), torch.Tensor)]
+            self.node_attrs[t] = {}
+            for k in keys:
+                self.node_attrs[t][k] = _Packed([getattr(g[t], k) for g in graphs], self.device)
+            self.node_counts[t] = np.array([int(g[t].num_nodes) for g in graphs], dtype=np.int64)
+            self.count_only[t] = "num_nodes" in g0[t] and "x" not in g0[t]
+        # edges: graph-local indices, [2][E_total]
+        self.edge_index: Dict[EdgeType, torch.Tensor] = {}
+        self.edge_ptr: Dict[EdgeType, torch.Tensor] = {}
+        self.edge_ptr_host: Dict[EdgeType, np.ndarray] = {}
+        self.edge_attr: Dict[EdgeType, _Packed] = {}
+        for e in self.edge_types:
+            eis = [g[e].edge_index.to(torch.int64) for g in graphs]
+            counts = np.array([int(ei.size(1)) for ei in eis], dtype=np.int64)
+            ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            self.edge_ptr_host[e] = ptr
+            self.edge_ptr[e] = torch.from_numpy(ptr).to(self.device)
+            self.edge_index[e] = torch.cat(eis, dim=1).contiguous().to(self.device)
+            if "edge_attr" in g0[e]:
+                self.edge_attr[e] = _Packed([g[e].edge_attr for g in graphs], self.device)
+        # staging buffer for the per-batch offset vectors (pinned: the H2D copy is asynchronous)
+        self._stage = None
+        self._stage_dev = None
+        self._copied = None  # event: the previous batch's offset copy has left the pinned buffer
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def collate(self, ids: Sequence[int]) -> HeteroData:
+        """Batch of graphs ``ids`` (in that order) on the device; equals ``data.collate([graphs[i] for i in ids]).to(device)``."""
+        sel_host = np.asarray(ids, dtype=np.int64)
+        B = int(sel_host.size)
+        assert B > 0 and sel_host.min() >= 0 and sel_host.max() < self.n_graphs
+        st = _lib.stream_ptr()
+        # ---- host: offsets of every node / edge type in the batch, packed into one int64 staging vector
+        node_off: Dict[str, np.ndarray] = {}
+        for t in self.node_types:
+            node_off[t] = np.concatenate([[0], np.cumsum(self.node_counts[t][sel_host])]).astype(np.int64)
+        edge_off: Dict[EdgeType, np.ndarray] = {}
+        for e in self.edge_types:
+            p = self.edge_ptr_host[e]
+            edge_off[e] = np.concatenate([[0], np.cumsum(p[sel_host + 1] - p[sel_host])]).astype(np.int64)
+        n_vec = len(self.node_types) + len(self.edge_types)
+        words = n_vec * (B + 1) + (B + 1) // 2 + 1  # + sel as int32
+        if self._copied is not None:
+            self._copied.synchronize()  # the pinned buffer is about to be rewritten
+        if self._stage is None or self._stage.numel() < words:
+            self._stage = torch.empty(max(words, 4096), dtype=torch.int64).pin_memory()
+            self._stage_dev = torch.empty_like(self._stage, device=self.device)
+            self._copied = torch.cuda.Event()
+        stage = self._stage.numpy()
+        pos, where = 0, {}
+        for key, vec in list(node_off.items()) + list(edge_off.items()):
+            stage[pos:pos + B + 1] = vec
+            where[key] = pos
+            pos += B + 1
+        sel32 = stage[pos:pos + (B + 1) // 2 + 1].view(np.int32)
+        sel32[:B] = sel_host.astype(np.int32)
+        sel_pos = pos
+        self._stage_dev[:words].copy_(self._stage[:words], non_blocking=True)
+        self._copied.record()
+        dev = self._stage_dev
+        sel_ptr = dev[sel_pos:].data_ptr()
+        off_ptr = lambda key: dev[where[key]:].data_ptr()
+
+        out = HeteroData()
+        out.num_graphs = B
+        lib = self.lib
+        for t in self.node_types:
+            n_out = int(node_off[t][-1])
+            for k, pk in self.node_attrs[t].items():
+                dst = torch.empty((n_out,) + pk.row_shape, dtype=pk.data.dtype, device=self.device)
+                _lib.check(lib.hmp_collate_rows(pk.data.data_ptr(), pk.row_bytes, pk.ptr.data_ptr(), sel_ptr, off_ptr(t), B, n_out,
+                                                dst.data_ptr(), st))
+                setattr(out[t], k, dst)
+            if self.count_only[t]:
+                out[t].num_nodes = n_out
+            ptr = dev[where[t]:where[t] + B + 1].clone()
+            out[t].ptr = ptr
+            out[t].batch = torch.repeat_interleave(torch.arange(B, dtype=torch.int64, device=self.device), ptr[1:] - ptr[:-1],
+                                                   output_size=n_out)
+        for e in self.edge_types:
+            e_out = int(edge_off[e][-1])
+            dst = torch.empty((2, e_out), dtype=torch.int64, device=self.device)
+            src = self.edge_index[e]
+            _lib.check(lib.hmp_collate_edges(src.data_ptr(), int(src.size(1)), self.edge_ptr[e].data_ptr(), sel_ptr, off_ptr(e),
+                                             off_ptr(e[0]), off_ptr(e[2]), B, e_out, dst.data_ptr(), st))
+            out[e].edge_index = dst
+            if e in self.edge_attr:
+                pk = self.edge_attr[e]
+                ea = torch.empty((e_out,) + pk.row_shape, dtype=pk.data.dtype, device=self.device)
+                _lib.check(lib.hmp_collate_rows(pk.data.data_ptr(), pk.row_bytes, self.edge_ptr[e].data_ptr(), sel_ptr, off_ptr(e), B, e_out,
+                                                ea.data_ptr(), st))
+                out[e].edge_attr = ea
+        return out

@@ -284,6 +284,19 @@ void hmp_timer_destroy(hmp_timer* t);
 int hmp_net_profile(hmp_net* net, int32_t enable);
 int hmp_net_profile_read(hmp_net* net, float* ms_sum /*[HMP_N_KCLASS]*/, int32_t* launches /*[HMP_N_KCLASS]*/);
 
+/* ---------------------------------------------------------------------------------------------
+ * 8. Device-side collation: replaces [PyG] DataLoader -> Batch.from_data_list + the per-step H2D copy
+ *    (base_training_job.py:164-178, :205).  The dataset lives in HBM as packed arrays; a batch = the graphs sel[0..B).
+ *    rows:  d_dst[d_dst_off[b] + i] = d_src[d_src_ptr[sel[b]] + i]            (row_bytes per row, multiple of 4)
+ *    edges: d_dst[r][d_dst_off[b] + j] = d_src[r][d_edge_ptr[sel[b]] + j] + (r ? d_off_dst : d_off_src)[b]
+ *           (d_src is [2][e_total] int64 with graph-local indices, d_dst is [2][e_out])
+ * ------------------------------------------------------------------------------------------- */
+int hmp_collate_rows(const void* d_src, int64_t row_bytes, const int64_t* d_src_ptr, const int32_t* d_sel,
+                     const int64_t* d_dst_off, int32_t B, int64_t n_out_rows, void* d_dst, void* stream);
+int hmp_collate_edges(const int64_t* d_src, int64_t e_total, const int64_t* d_edge_ptr, const int32_t* d_sel,
+                      const int64_t* d_dst_off, const int64_t* d_off_src, const int64_t* d_off_dst, int32_t B,
+                      int64_t e_out, int64_t* d_dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
