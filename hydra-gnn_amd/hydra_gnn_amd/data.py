@@ -68,6 +68,7 @@ class _Store:
 
     def __init__(self) -> None:
         object.__setattr__(self, "_d", {})
+        object.__setattr__(self, "_v", 0)  # bumped on every attribute assignment (lets the engine cache a batch descriptor)
 
     def __getattr__(self, name):
         d = object.__getattribute__(self, "_d")
@@ -88,6 +89,7 @@ class _Store:
 
     def __setattr__(self, name, value):
         object.__getattribute__(self, "_d")[name] = value
+        object.__setattr__(self, "_v", object.__getattribute__(self, "_v") + 1)
 
     def __contains__(self, name):
         return name in object.__getattribute__(self, "_d")
@@ -123,6 +125,15 @@ class HeteroData:
         if key not in self._nodes:
             self._nodes[key] = _Store()
         return self._nodes[key]
+
+    def _mutation_stamp(self) -> int:
+        """changes whenever a store is added or an attribute of any store is (re)assigned"""
+        v = len(self._nodes) + len(self._edges)
+        for s in self._nodes.values():
+            v += object.__getattribute__(s, "_v") << 8
+        for s in self._edges.values():
+            v += object.__getattribute__(s, "_v") << 8
+        return v
 
     @property
     def node_types(self) -> List[str]:

@@ -214,14 +214,17 @@ class NativeNet:
             pass
 
     # ---- flat parameters -------------------------------------------------------------------------
-    def flat_params(self) -> torch.Tensor:
+    def flat_params(self, full_check: bool = True) -> torch.Tensor:
         """The flat fp32 buffer the named parameters are views of (re-created after ``.to()``)."""
         p0 = self.params[0]
         _require_cuda(p0.data, "model parameters")
         ok = self._flat is not None and self._flat.device == p0.device
         if ok:
             base = self._flat.data_ptr()
-            for p in self.params:
+            # `.to()` / `.float()` re-home every parameter; the first and the last one are checked on the hot path (one call
+            # per step), all of them when the check is forced
+            probe = self.params if full_check else (self.params[0], self.params[-1])
+            for p in probe:
                 if p.data.data_ptr() != base + 4 * self.param_offsets[id(p)] or p.dtype != torch.float32:
                     ok = False
                     break
@@ -409,6 +412,8 @@ class TrainStep:
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self._holder = None
+        self._batch_key = None
+        self._data_ref = None
 
     def _world(self) -> int:
         if self.pg is None:
@@ -442,9 +447,18 @@ class TrainStep:
 
     def __call__(self, data, labels: torch.Tensor) -> None:
         net = self.net
-        if net.flat_params() is not self.flat:
+        if net.flat_params(full_check=False) is not self.flat:
             raise _lib.HydraMPError("model parameters were moved after TrainStep was created")
-        h = net.make_batch(self.view(data) if self.view is not None else data, labels)
+        # the batch descriptor of an unchanged batch object is reused (hydra_gnn_amd.data.HeteroData stamps every mutation;
+        # foreign containers are described afresh every step)
+        stamp = getattr(data, "_mutation_stamp", None)
+        key = (id(data), stamp(), id(labels), labels._version) if stamp is not None else None
+        if key is not None and key == self._batch_key:
+            h = self._holder
+        else:
+            h = net.make_batch(self.view(data) if self.view is not None else data, labels)
+            self._batch_key = key
+            self._data_ref = (data, labels)  # keeps id() unique while the key is live
         dev = self.flat.device
         with torch.cuda.device(dev):
             net._ensure_workspace(h, dev)
