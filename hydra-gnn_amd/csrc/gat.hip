@@ -68,22 +68,27 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// raw (pre-leaky) logits of one neighbour for all heads
+// raw (pre-leaky) logits of one neighbour for all heads.  `ea` is uniform (null: the conv has no edge attributes); `use`
+// masks the edge term of this slot (virtual self loops carry zero attributes, dead batch slots nothing) WITHOUT a branch
+// around the loads: eid is clamped to a valid edge by the caller.
 template <int HM>
 __device__ __forceinline__ void edge_logits(const GatInS& I, const float* ea, int H, const float* aj, const float (&ad)[HM],
-                                            const float (&ve)[GAT_MAX_EDIM][HM], bool with_edge, int eid, float (&raw)[HM]) {
+                                            const float (&ve)[GAT_MAX_EDIM][HM], bool use, int eid, float (&raw)[HM]) {
   float x[GAT_MAX_EDIM] = {0.f, 0.f, 0.f, 0.f};
-  if (with_edge) {
+  if (ea) {  // uniform
 #pragma unroll
     for (int d = 0; d < GAT_MAX_EDIM; ++d)
-      if (d < I.edim) x[d] = ea[(int64_t)eid * I.edim + d];
+      if (d < I.edim) {
+        const float t = ea[(int64_t)eid * I.edim + d];
+        x[d] = use ? t : 0.f;
+      }
   }
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
     float r = 0.f;
     if (h < H) {
       r = aj[I.asoff + h] + ad[h];
-      if (with_edge) {
+      if (ea) {
 #pragma unroll
         for (int d = 0; d < GAT_MAX_EDIM; ++d) r += x[d] * ve[d][h];
       }
@@ -100,6 +105,48 @@ __device__ __forceinline__ void load_row_consts(const GatInS& I, int H, int row,
   for (int d = 0; d < GAT_MAX_EDIM; ++d)
 #pragma unroll
     for (int h = 0; h < HM; ++h) ve[d][h] = (I.vedge && d < I.edim && h < H) ? I.vedge[d * GAT_HMAX + h] : 0.f;
+}
+
+// A batch of UB consecutive neighbour slots k0 .. k0+UB-1 of one destination row (real edges [b, e), then the virtual self
+// loop at k == e when kend > e): neighbour ids and edge ids first (one round trip), then everything that depends on them
+// -- attention logits (a_s of the neighbour, edge attributes) and the neighbour's H head slices of this lane -- in flight
+// together (second round trip).  The per-edge arithmetic that follows is the sequential code's, edge by edge, in the same
+// order: results are bit-identical to the unbatched kernels, the dependent chain is 2 round trips per UB edges instead of
+// 2 per edge.  Slots outside the row are clamped to valid addresses and flagged dead.
+template <int HM, int UB>
+struct EdgeBatch {
+  int j[UB], eid[UB];
+  bool live[UB], loop[UB], removed[UB];  // removed: an explicit self loop that add_self_loops replaces (PyG remove_self_loops)
+  float raw[UB][HM];
+  float4 v[UB][HM];
+};
+
+template <int HM, int UB>
+__device__ __forceinline__ void fetch_batch(const GatInS& I, int Cp, const float* __restrict__ ea, int H, int row, int b, int e, int kend,
+                                            int k0, int cc, const float (&ad)[HM], const float (&ve)[GAT_MAX_EDIM][HM],
+                                            EdgeBatch<HM, UB>& B) {
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int k = k0 + u;
+    const bool in = k < kend;
+    const bool lp = in && k >= e;
+    const int kc = (e > b) ? min(k, e - 1) : 0;
+    const int cj = I.col[kc];
+    const int ce = ea ? I.eid[kc] : 0;
+    const bool real = in && !lp;
+    B.loop[u] = lp;
+    B.j[u] = lp ? row : (real ? cj : 0);  // dead slots read row 0 (always allocated), never used
+    B.eid[u] = real ? ce : 0;
+    B.removed[u] = real && I.self_loops && cj == row;
+    B.live[u] = in && !B.removed[u];
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    edge_logits<HM>(I, ea, H, I.za + (int64_t)B.j[u] * I.ldza, ad, ve, !B.loop[u] && B.live[u], B.eid[u], B.raw[u]);
+    const float* zj = I.z + (int64_t)B.j[u] * I.ldz + I.hoff + cc;
+#pragma unroll
+    for (int h = 0; h < HM; ++h) B.v[u][h] = (h < H) ? ld4(zj + h * Cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // =================================================================================================
@@ -125,7 +172,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
     const GatInS& I = D.in[ii];
     const int64_t E = dyn.n_edges[I.et];
     const int n_loop = I.self_loops ? min(dyn.n_nodes[I.src_t], dyn.n_nodes[D.t]) : 0;
-    const float* ea = (I.edim > 0) ? dyn.edge_attr[I.et] : nullptr;
+    const float* ea = (I.edim > 0 && E > 0) ? dyn.edge_attr[I.et] : nullptr;  // dead batch slots read attribute row 0
     float ad[HM], ve[GAT_MAX_EDIM][HM];
     load_row_consts<HM>(I, H, row, ad, ve);
     const bool adrop = dyn.training && I.adrop_p > 0.f;
@@ -139,35 +186,37 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
 
     const int b = I.rowptr[row], e = I.rowptr[row + 1];
     const int kend = e + ((row < n_loop) ? 1 : 0);
-    for (int k = b; k < kend; ++k) {
-      const bool is_loop = k >= e;
-      const int j = is_loop ? row : I.col[k];
-      if (I.self_loops && !is_loop && j == row) continue;
-      const float* zj = I.z + (int64_t)j * I.ldz;
-      float raw[HM];
-      edge_logits<HM>(I, ea, H, I.za + (int64_t)j * I.ldza, ad, ve, ea != nullptr && !is_loop, is_loop ? 0 : I.eid[k], raw);
-      bool keep[HM];
+    constexpr int UB = (HM <= 4) ? 4 : 2;
+    const int cc = cact ? c0 : 0;
+    for (int k0 = b; k0 < kend; k0 += UB) {
+      EdgeBatch<HM, UB> B;
+      fetch_batch<HM, UB>(I, D.Cp, ea, H, row, b, e, kend, k0, cc, ad, ve, B);
 #pragma unroll
-      for (int h = 0; h < HM; ++h) keep[h] = true;
-      if (adrop) alpha_keep<HM>(acfg, is_loop ? (E + row) : (int64_t)k, keep);
+      for (int u = 0; u < UB; ++u) {
+        if (!B.live[u]) continue;
+        bool keep[HM];
 #pragma unroll
-      for (int h = 0; h < HM; ++h) {
-        if (h >= H) continue;
-        const float ev = raw[h] > 0.f ? raw[h] : NEG_SLOPE * raw[h];
-        const float mn = fmaxf(m[h], ev);
-        const float sc = expf(m[h] - mn);
-        const float p = expf(ev - mn);
-        s[h] = s[h] * sc + p;
-        float w = p;
-        if (adrop) w = keep[h] ? p * acfg.scale : 0.f;
-        if (cact) {
-          const float4 v = ld4(zj + I.hoff + h * D.Cp + c0);
-          acc[h].x = acc[h].x * sc + w * v.x;
-          acc[h].y = acc[h].y * sc + w * v.y;
-          acc[h].z = acc[h].z * sc + w * v.z;
-          acc[h].w = acc[h].w * sc + w * v.w;
+        for (int h = 0; h < HM; ++h) keep[h] = true;
+        if (adrop) alpha_keep<HM>(acfg, B.loop[u] ? (E + row) : (int64_t)(k0 + u), keep);
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+          if (h >= H) continue;
+          const float ev = B.raw[u][h] > 0.f ? B.raw[u][h] : NEG_SLOPE * B.raw[u][h];
+          const float mn = fmaxf(m[h], ev);
+          const float sc = expf(m[h] - mn);
+          const float p = expf(ev - mn);
+          s[h] = s[h] * sc + p;
+          float w = p;
+          if (adrop) w = keep[h] ? p * acfg.scale : 0.f;
+          if (cact) {
+            const float4 v = B.v[u][h];
+            acc[h].x = acc[h].x * sc + w * v.x;
+            acc[h].y = acc[h].y * sc + w * v.y;
+            acc[h].z = acc[h].z * sc + w * v.z;
+            acc[h].w = acc[h].w * sc + w * v.w;
+          }
+          m[h] = mn;
         }
-        m[h] = mn;
       }
     }
 #pragma unroll
@@ -266,7 +315,7 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
     const GatInS& I = D.in[ii];
     const int64_t E = dyn.n_edges[I.et];
     const int n_loop = I.self_loops ? min(dyn.n_nodes[I.src_t], dyn.n_nodes[D.t]) : 0;
-    const float* ea = (I.edim > 0) ? dyn.edge_attr[I.et] : nullptr;
+    const float* ea = (I.edim > 0 && E > 0) ? dyn.edge_attr[I.et] : nullptr;  // dead batch slots read attribute row 0
     float ad[HM], ve[GAT_MAX_EDIM][HM], m[HM], den[HM];
     load_row_consts<HM>(I, H, row, ad, ve);
 #pragma unroll
@@ -284,50 +333,55 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
 #pragma unroll
     for (int h = 0; h < HM; ++h) { tsum[h] = 0.f; dsum[h] = 0.f; }
 
+    constexpr int UB = (HM <= 4) ? 4 : 2;
+    const int cc = cact ? c0 : 0;
     for (int sweep = 0; sweep < 2; ++sweep) {
-      for (int k = b; k < kend; ++k) {
-        const bool is_loop = k >= e;
-        const int j = is_loop ? row : I.col[k];
-        const int64_t pos = is_loop ? (E + row) : (int64_t)k;
-        if (I.self_loops && !is_loop && j == row) {  // removed self loop: contributes nothing
-          if (sweep == 1 && gl == 0) {
+      for (int k0 = b; k0 < kend; k0 += UB) {
+        EdgeBatch<HM, UB> B;
+        fetch_batch<HM, UB>(I, D.Cp, ea, H, row, b, e, kend, k0, cc, ad, ve, B);
 #pragma unroll
-            for (int h = 0; h < HM; ++h)
-              if (h < H) {
-                I.alpha_drop[pos * GAT_HMAX + h] = 0.f;
-                I.dlogit[pos * GAT_HMAX + h] = 0.f;
-                if (I.dlogit_orig) I.dlogit_orig[(int64_t)I.eid[k] * GAT_HMAX + h] = 0.f;
-              }
+        for (int u = 0; u < UB; ++u) {
+          const int k = k0 + u;
+          const int64_t pos = B.loop[u] ? (E + row) : (int64_t)k;
+          if (B.removed[u]) {  // removed self loop: contributes nothing
+            if (sweep == 1 && gl == 0) {
+#pragma unroll
+              for (int h = 0; h < HM; ++h)
+                if (h < H) {
+                  I.alpha_drop[pos * GAT_HMAX + h] = 0.f;
+                  I.dlogit[pos * GAT_HMAX + h] = 0.f;
+                  if (I.dlogit_orig) I.dlogit_orig[(int64_t)I.eid[k] * GAT_HMAX + h] = 0.f;
+                }
+            }
+            continue;
           }
-          continue;
-        }
-        const float* zj = I.z + (int64_t)j * I.ldz;
-        float raw[HM];
-        edge_logits<HM>(I, ea, H, I.za + (int64_t)j * I.ldza, ad, ve, ea != nullptr && !is_loop, is_loop ? 0 : I.eid[k], raw);
-        bool keep[HM];
+          if (!B.live[u]) continue;
+          bool keep[HM];
 #pragma unroll
-        for (int h = 0; h < HM; ++h) keep[h] = true;
-        if (adrop) alpha_keep<HM>(acfg, pos, keep);
+          for (int h = 0; h < HM; ++h) keep[h] = true;
+          if (adrop) alpha_keep<HM>(acfg, pos, keep);
 #pragma unroll
-        for (int h = 0; h < HM; ++h) {
-          if (h >= H) continue;
-          float part = 0.f;
-          if (cact) part = dot4(g[h], ld4(zj + I.hoff + h * D.Cp + c0));
-          const float dap = group_sum<GS>(part);  // d alpha'_k,h (identical in every lane of the group)
-          const float ev = raw[h] > 0.f ? raw[h] : NEG_SLOPE * raw[h];
-          const float alpha = expf(ev - m[h]) / den[h];
-          const float dscale = adrop ? (keep[h] ? acfg.scale : 0.f) : 1.f;
-          const float da = dap * dscale;
-          if (sweep == 0) {
-            tsum[h] += alpha * da;
-          } else {
-            const float de = alpha * (da - tsum[h]);
-            const float dl = de * (raw[h] > 0.f ? 1.f : NEG_SLOPE);
-            dsum[h] += dl;
-            if (gl == 0) {
-              I.alpha_drop[pos * GAT_HMAX + h] = alpha * dscale;
-              I.dlogit[pos * GAT_HMAX + h] = dl;
-              if (I.dlogit_orig && !is_loop) I.dlogit_orig[(int64_t)I.eid[k] * GAT_HMAX + h] = dl;
+          for (int h = 0; h < HM; ++h) {
+            if (h >= H) continue;
+            float part = 0.f;
+            if (cact) part = dot4(g[h], B.v[u][h]);
+            const float dap = group_sum<GS>(part);  // d alpha'_k,h (identical in every lane of the group)
+            const float rw = B.raw[u][h];
+            const float ev = rw > 0.f ? rw : NEG_SLOPE * rw;
+            const float alpha = expf(ev - m[h]) / den[h];
+            const float dscale = adrop ? (keep[h] ? acfg.scale : 0.f) : 1.f;
+            const float da = dap * dscale;
+            if (sweep == 0) {
+              tsum[h] += alpha * da;
+            } else {
+              const float de = alpha * (da - tsum[h]);
+              const float dl = de * (rw > 0.f ? 1.f : NEG_SLOPE);
+              dsum[h] += dl;
+              if (gl == 0) {
+                I.alpha_drop[pos * GAT_HMAX + h] = alpha * dscale;
+                I.dlogit[pos * GAT_HMAX + h] = dl;
+                if (I.dlogit_orig && !B.loop[u]) I.dlogit_orig[(int64_t)B.eid[u] * GAT_HMAX + h] = dl;
+              }
             }
           }
         }
@@ -370,25 +424,62 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
     for (int h = 0; h < HM; ++h) { acc[h] = make_float4(0.f, 0.f, 0.f, 0.f); das[h] = 0.f; }
     const int b = I.t_rowptr[row], e = I.t_rowptr[row + 1];
     const int kend = e + ((row < n_loop) ? 1 : 0);
-    for (int k = b; k < kend; ++k) {
-      const bool is_loop = k >= e;
-      const int i = is_loop ? row : I.t_col[k];
-      const int64_t pos = is_loop ? (E + row) : (int64_t)I.t_pos[k];
-      const float* gr = gp + (int64_t)i * ldg;
+    // out-edges in batches of 4: destination ids + CSR positions first, then the per-edge scalars and gradient rows of the
+    // whole batch in flight together; the adds keep the edge order
+    constexpr int UB = (HM <= 4) ? 4 : 2;
+    for (int k0 = b; k0 < kend; k0 += UB) {
+      int ii[UB];
+      int64_t pp[UB];
+      bool in[UB];
 #pragma unroll
-      for (int h = 0; h < HM; ++h) {
-        if (h >= H) continue;
-        const float ap = I.alpha_drop[pos * GAT_HMAX + h];
-        das[h] += I.dlogit[pos * GAT_HMAX + h];
-        if (cact) {
+      for (int u = 0; u < UB; ++u) {
+        const int k = k0 + u;
+        in[u] = k < kend;
+        const bool lp = in[u] && k >= e;
+        const int kc = (e > b) ? min(k, e - 1) : 0;
+        const int ti = I.t_col[kc];
+        const int tp = I.t_pos[kc];
+        const bool real = in[u] && !lp;
+        ii[u] = lp ? row : (real ? ti : 0);
+        pp[u] = lp ? (E + row) : (real ? (int64_t)tp : 0);
+      }
+      float ap[UB][HM], dl[UB][HM];
+      float4 gv[UB][HM];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const float* gr = gp + (int64_t)ii[u] * ldg;
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+          ap[u][h] = (h < H) ? I.alpha_drop[pp[u] * GAT_HMAX + h] : 0.f;
+          dl[u][h] = (h < H) ? I.dlogit[pp[u] * GAT_HMAX + h] : 0.f;
           float t4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (cact && h < H && (D.concat || h == 0)) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = c0 + q;
-            if (c < D.C) t4[q] = D.concat ? gr[h * D.C + c] : gr[c] / (float)H;
+            for (int q = 0; q < 4; ++q) {
+              const int c = c0 + q;
+              if (c < D.C) t4[q] = D.concat ? gr[h * D.C + c] : gr[c];
+            }
           }
-          const float w = ap * D.group_scale;
-          acc[h].x += w * t4[0]; acc[h].y += w * t4[1]; acc[h].z += w * t4[2]; acc[h].w += w * t4[3];
+          gv[u][h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (!in[u]) continue;
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+          if (h >= H) continue;
+          das[h] += dl[u][h];
+          if (cact) {
+            const float4 gq = D.concat ? gv[u][h] : gv[u][0];
+            const float w = ap[u][h] * D.group_scale;
+            if (D.concat) {
+              acc[h].x += w * gq.x; acc[h].y += w * gq.y; acc[h].z += w * gq.z; acc[h].w += w * gq.w;
+            } else {
+              const float fh = (float)H;
+              acc[h].x += w * (gq.x / fh); acc[h].y += w * (gq.y / fh); acc[h].z += w * (gq.z / fh); acc[h].w += w * (gq.w / fh);
+            }
+          }
         }
       }
     }
