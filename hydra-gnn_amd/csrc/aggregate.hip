@@ -27,6 +27,7 @@ struct Acc<4> {
   __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
   __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
   __device__ __forceinline__ void add_div(const Acc& o, float d) { v.x += o.v.x / d; v.y += o.v.y / d; v.z += o.v.z / d; v.w += o.v.w / d; }
+  __device__ __forceinline__ void add_mul(const Acc& o, float r) { v.x += o.v.x * r; v.y += o.v.y * r; v.z += o.v.z * r; v.w += o.v.w * r; }
   __device__ __forceinline__ void div(float d) { v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
   __device__ __forceinline__ float& at(int i) { return (&v.x)[i]; }
 };
@@ -38,6 +39,7 @@ struct Acc<1> {
   __device__ __forceinline__ void store(float* p) const { *p = v; }
   __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
   __device__ __forceinline__ void add_div(const Acc& o, float d) { v += o.v / d; }
+  __device__ __forceinline__ void add_mul(const Acc& o, float r) { v += o.v * r; }
   __device__ __forceinline__ void div(float d) { v /= d; }
   __device__ __forceinline__ float& at(int) { return v; }
 };
@@ -75,12 +77,13 @@ __device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __r
   }
 }
 
-// sum_k g[tcol[k]][c..] / max(deg(tcol[k]),1)  (backward of the mean: every edge carries 1/deg(dst)).
-// `degf` (float max(deg,1) per destination, written by the plan) removes the two dependent rowptr loads per edge; without
-// it (unit entry point) the degree is derived from rowptr.  Same clamped batches as gather_sum.
+// sum_k g[tcol[k]][c..] * rdeg(tcol[k])  (backward of the mean: every edge carries 1 / max(deg(dst), 1)).
+// `rdeg` (the reciprocal per destination, written by the plan) removes the two dependent rowptr loads per edge AND the
+// per-edge fp32 divisions (4 per lane and edge: ~1 ms of the config-5 transposed aggregation); without it (unit entry
+// point) the reciprocal is derived from rowptr.  Same clamped batches as gather_sum.
 template <int GS, int NV, int VEC>
 __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* __restrict__ g, int ld, const int* __restrict__ tcol,
-                                             const int* __restrict__ rowptr, const float* __restrict__ degf, int mean, int b, int e,
+                                             const int* __restrict__ rowptr, const float* __restrict__ rdeg, int mean, int b, int e,
                                              int c0, int F) {
   constexpr int UB = (NV == 1) ? 8 : 4;
   for (int k = b; k < e; k += UB) {
@@ -92,11 +95,11 @@ __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* _
     for (int u = 0; u < UB; ++u) {
       d[u] = 1.f;
       if (mean) {
-        if (degf) {
-          d[u] = degf[i[u]];
+        if (rdeg) {
+          d[u] = rdeg[i[u]];
         } else {
           const int deg = rowptr[i[u] + 1] - rowptr[i[u]];
-          d[u] = (float)(deg > 1 ? deg : 1);
+          d[u] = 1.f / (float)(deg > 1 ? deg : 1);
         }
       }
     }
@@ -116,7 +119,7 @@ __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* _
         for (int q = 0; q < NV; ++q) {
           const int c = c0 + q * GS * VEC;
           if (c < F) {
-            if (mean) acc[q].add_div(v[u][q], d[u]); else acc[q].add(v[u][q]);
+            if (mean) acc[q].add_mul(v[u][q], d[u]); else acc[q].add(v[u][q]);
           }
         }
       }
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
     if (oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
   }
   if constexpr (NV == 1) {
-    // outgoing edge types in PAIRS (see agg_row): ids of both, then degrees + gradient rows of both
+    // outgoing edge types in PAIRS (see agg_row): ids of both, then 1/deg + gradient rows of both
     constexpr int UB = 8;
 #pragma unroll
     for (int oi = 0; oi < AGG_MAX_IN; oi += 2) {
@@ -488,8 +491,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           const int g0 = O0.rowptr[i0[u] + 1] - O0.rowptr[i0[u]], g1 = O1.rowptr[i1[u] + 1] - O1.rowptr[i1[u]];
-          d0[u] = (float)(g0 > 1 ? g0 : 1);
-          d1[u] = (float)(g1 > 1 ? g1 : 1);
+          d0[u] = 1.f / (float)(g0 > 1 ? g0 : 1);
+          d1[u] = 1.f / (float)(g1 > 1 ? g1 : 1);
         }
       }
       Acc<VEC> a0[1], a1[1];
@@ -497,10 +500,10 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       a1[0].zero();
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (b0 + u < e0) a0[0].add_div(v0[u], d0[u]);
+        if (b0 + u < e0) a0[0].add_mul(v0[u], d0[u]);
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (b1 + u < e1) a1[0].add_div(v1[u], d1[u]);
+        if (b1 + u < e1) a1[0].add_mul(v1[u], d1[u]);
       if (e0 - b0 > UB) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + UB, e0, c0, O0.F);
       if (e1 - b1 > UB) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + UB, e1, c0, O1.F);
       if (c0 < O0.F) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
       rb[oi] = re[oi] = 0;
       if (live && oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
     }
-    // outgoing edge types in PAIRS (see agg_row): ids of both, then degrees + gradient rows of both
+    // outgoing edge types in PAIRS (see agg_row): ids of both, then 1/deg + gradient rows of both
     constexpr int UB = 8;
 #pragma unroll
     for (int oi = 0; oi < AGG_MAX_IN; oi += 2) {
@@ -602,8 +605,8 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           const int g0 = O0.rowptr[i0[u] + 1] - O0.rowptr[i0[u]], g1 = O1.rowptr[i1[u] + 1] - O1.rowptr[i1[u]];
-          d0[u] = (float)(g0 > 1 ? g0 : 1);
-          d1[u] = (float)(g1 > 1 ? g1 : 1);
+          d0[u] = 1.f / (float)(g0 > 1 ? g0 : 1);
+          d1[u] = 1.f / (float)(g1 > 1 ? g1 : 1);
         }
       }
       Acc<VEC> a0[1], a1[1];
@@ -611,10 +614,10 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
       a1[0].zero();
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (b0 + u < e0) a0[0].add_div(v0[u], d0[u]);
+        if (b0 + u < e0) a0[0].add_mul(v0[u], d0[u]);
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (b1 + u < e1) a1[0].add_div(v1[u], d1[u]);
+        if (b1 + u < e1) a1[0].add_mul(v1[u], d1[u]);
       if (e0 - b0 > UB) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + UB, e0, c0, O0.F);
       if (e1 - b1 > UB) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + UB, e1, c0, O1.F);
       if (c0 < O0.F) {

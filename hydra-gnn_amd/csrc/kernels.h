@@ -110,7 +110,7 @@ struct PlanJob {
   int64_t E;
   int n_src, n_dst;
   int *rowptr, *col, *eid, *t_rowptr, *t_col, *t_pos;
-  float* degf;  // optional [n_dst]: max(in-degree, 1) as float
+  float* degf;  // optional [n_dst]: 1 / max(in-degree, 1) as float
   // scratch
   int *cnt_in, *cnt_out, *cur_in, *cur_out;  // must be zero on entry (one contiguous block); left zero on exit
   int *tmp_in, *tmp_out, *t_eid, *pos_of_eid;
@@ -178,7 +178,7 @@ struct TAggOut {
   const int* t_rowptr;
   const int* t_col;
   const int* rowptr;  // forward CSR rowptr of the same edge type (for 1/deg of the destination)
-  const float* degf;  // max(deg,1) per destination as float (plan by-product), null: derive from rowptr
+  const float* degf;  // 1 / max(deg,1) per destination (plan by-product), null: derive from rowptr
   const float* g;     // gradient rows of the destination type
   int ldg, coff, F;
 };

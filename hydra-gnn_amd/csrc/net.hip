@@ -92,7 +92,7 @@ struct hmp_net {
   int n_pack_blocks16 = 0;
   char* ws_base = nullptr;
   size_t ws_bytes = 0;
-  float* degf[HMP_MAX_EDGE_TYPES];  // max(in-degree,1) per destination node, by-product of the plan
+  float* degf[HMP_MAX_EDGE_TYPES];  // 1 / max(in-degree,1) per destination node, by-product of the plan
   float* d_row_lv = nullptr;        // per output row {loss, valid} of the fused step's loss kernel
   bool fin_loss = false;            // the next gradient un-pack also finalises {loss_sum, count}
 

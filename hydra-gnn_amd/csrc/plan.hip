@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
     if (lane == 0) {
       // this wave is the last reader of the row's counters: leave them zero for the next build
       if (dir) { J.cnt_out[row] = 0; J.cur_out[row] = 0; }
-      else { J.cnt_in[row] = 0; J.cur_in[row] = 0; if (J.degf) J.degf[row] = (float)(deg > 1 ? deg : 1); }
+      else { J.cnt_in[row] = 0; J.cur_in[row] = 0; if (J.degf) J.degf[row] = 1.f / (float)(deg > 1 ? deg : 1); }
     }
     for (int c = lane; c < deg; c += 64) {
       const int mine = tmp[b + c];

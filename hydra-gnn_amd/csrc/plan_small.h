@@ -130,7 +130,7 @@ __device__ __forceinline__ void plan_small_part(const PlanJob& J, int dir, int p
     if (tid < nr) {
       lrow[tid] = excl;
       (dir ? J.t_rowptr : J.rowptr)[r0 + tid] = base + excl;
-      if (!dir && J.degf) J.degf[r0 + tid] = (float)(v > 1 ? v : 1);
+      if (!dir && J.degf) J.degf[r0 + tid] = 1.f / (float)(v > 1 ? v : 1);
       cnt[tid] = 0;  // becomes the row cursor of pass 2
     }
     if (tid == 1023) s_total = woff + x;
