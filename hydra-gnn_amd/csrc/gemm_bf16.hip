@@ -7,8 +7,8 @@
 // explicit precision mode (hmp_net_spec.compute_bf16): results differ from the fp32 path by bf16 input rounding
 // (~2^-9 relative per product), so it is NOT used for the 1e-5 parity configurations.
 //
-// Block = 4 waves, tile 128x128, K stage 32; every wave owns a 64x64 quadrant = 2x2 MFMA tiles (64 accumulator
-// registers).  LDS images are [row][k] in bf16 with a pitch of 40 elements (80 bytes: 16-byte aligned rows), so an MFMA
+// Block = 4 waves, tile 128x128, K stage 64; every wave owns a 64x64 quadrant = 2x2 MFMA tiles (64 accumulator
+// registers).  LDS images are [row][k] in bf16 with a pitch of 72 elements (144 bytes: 16-byte aligned rows), so an MFMA
 // operand (8 consecutive k of one row) is one ds_read_b128.  A k-contiguous operand ([row][k] in memory) is loaded as
 // float4 along k (one 8-byte LDS write each) into a [row][k] image.  A row-contiguous operand ([k][row]: the weight-
 // gradient form, both operands) is loaded as float4 along rows into the NATURAL [k][row] image (8-byte writes) and
@@ -27,25 +27,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BT = 128;      // tile edge
-constexpr int BKB = 32;      // K stage
-constexpr int BPITCH = 40;   // bf16 elements per row of a [row][k] image (80 bytes: 16-byte aligned rows)
-constexpr int BRPITCH = 136; // bf16 elements per k row of a [k][row] image (272 bytes: 8-byte aligned)
-constexpr int BLDS = BT * BPITCH > BKB * BRPITCH ? BT * BPITCH : BKB * BRPITCH;
-
+// K stage BK (64 for the 128x128 tile, 32 for the 256x256 tile: 8 / 4 float4 slots per thread, operand and stage);
+// [row][k] images have a pitch of BK + 8 bf16 elements (16-byte aligned rows)
+template <int NV>
 struct StageRegs {
-  float4 v[4];
+  float4 v[NV];
 };
 
-// fast loader: the tile is interior in the vectorised direction and every row start is 16-byte aligned.
-//  kcontig: slot q covers row q / 8, k4 = (q % 8) * 4      rcontig: slot q covers k = q / 32, r4 = (q % 32) * 4
-__device__ __forceinline__ void bf_load_fast(StageRegs& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int k0, int kend) {
+// Block shapes <NT threads, ROWS x ROWS tile>: <256, 128> (4 waves, 2x2, 64x64 per wave) and <512, 256> (8 waves, 4x2,
+// 64x128 per wave).  The big tile exists because these GEMMs are bound by L2 -> CU operand traffic (~4.7 TB/s aggregate
+// measured): a 128x128 tile re-reads A once per 128 output columns and B once per 128 output rows (12 GB for the config-5
+// layer-0 projection), a 256x256 tile halves both.
+//  kcontig: slot q covers row q / 16, k4 = (q % 16) * 4      rcontig: slot q covers k = q / (ROWS/4), r4 = (q % (ROWS/4)) * 4
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_load_fast(StageRegs<ROWS * BKB / 4 / NT>& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R,
+                                             int k0, int kend) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < BNV; ++i) {
+    const int q = tid + i * NT;
     if (kcontig) {
-      const int r = q >> 3, k4 = (q & 7) * 4;
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
       const int gr = r0 + r, gk = k0 + k4;
       const bool rl = gr < R;
       const int gkc = gk < kend ? gk : k0;
@@ -53,7 +56,7 @@ __device__ __forceinline__ void bf_load_fast(StageRegs& t, const float* __restri
       t.v[i] = make_float4(rl && gk + 0 < kend ? val.x : 0.f, rl && gk + 1 < kend ? val.y : 0.f, rl && gk + 2 < kend ? val.z : 0.f,
                            rl && gk + 3 < kend ? val.w : 0.f);
     } else {
-      const int k = q >> 5, r4 = (q & 31) * 4;
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
       const int gk = k0 + k;
       const bool kl = gk < kend;
       const float4 val = *reinterpret_cast<const float4*>(p + (int64_t)(kl ? gk : k0) * ld + (r0 + r4));
@@ -63,15 +66,17 @@ __device__ __forceinline__ void bf_load_fast(StageRegs& t, const float* __restri
 }
 
 // edge loader: element by element with bounds (last column tile, ones column, unaligned operands)
-__device__ __forceinline__ void bf_load_edge(StageRegs& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int n_real, int aug,
-                                             int k0, int kend) {
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_load_edge(StageRegs<ROWS * BKB / 4 / NT>& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R,
+                                             int n_real, int aug, int k0, int kend) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < BNV; ++i) {
+    const int q = tid + i * NT;
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     if (kcontig) {
-      const int r = q >> 3, k4 = (q & 7) * 4;
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
       const int gr = r0 + r;
       if (gr < R) {
 #pragma unroll
@@ -79,7 +84,7 @@ __device__ __forceinline__ void bf_load_edge(StageRegs& t, const float* __restri
           if (k0 + k4 + j < kend) e[j] = p[(int64_t)gr * ld + k0 + k4 + j];
       }
     } else {  // columns past n_real are zero, the ones column is virtual
-      const int k = q >> 5, r4 = (q & 31) * 4;
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
       const int gk = k0 + k;
       if (gk < kend) {
 #pragma unroll
@@ -93,21 +98,23 @@ __device__ __forceinline__ void bf_load_edge(StageRegs& t, const float* __restri
   }
 }
 
-__device__ __forceinline__ void bf_store(const StageRegs& t, __bf16* __restrict__ s, int kcontig) {
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_store(const StageRegs<ROWS * BKB / 4 / NT>& t, __bf16* __restrict__ s, int kcontig) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
+  constexpr int BPITCH = BKB + 8;
+  constexpr int RP = ROWS + 8;  // bf16 elements per k row of a [k][row] image (8-byte aligned rows)
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < BNV; ++i) {
+    const int q = tid + i * NT;
+    bf16x4 b;
+    b[0] = (__bf16)t.v[i].x; b[1] = (__bf16)t.v[i].y; b[2] = (__bf16)t.v[i].z; b[3] = (__bf16)t.v[i].w;
     if (kcontig) {
-      const int r = q >> 3, k4 = (q & 7) * 4;
-      bf16x4 b;
-      b[0] = (__bf16)t.v[i].x; b[1] = (__bf16)t.v[i].y; b[2] = (__bf16)t.v[i].z; b[3] = (__bf16)t.v[i].w;
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
       *reinterpret_cast<bf16x4*>(s + r * BPITCH + k4) = b;
     } else {  // natural [k][row] image
-      const int k = q >> 5, r4 = (q & 31) * 4;
-      bf16x4 b;
-      b[0] = (__bf16)t.v[i].x; b[1] = (__bf16)t.v[i].y; b[2] = (__bf16)t.v[i].z; b[3] = (__bf16)t.v[i].w;
-      *reinterpret_cast<bf16x4*>(s + k * BRPITCH + r4) = b;
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      *reinterpret_cast<bf16x4*>(s + k * RP + r4) = b;
     }
   }
 }
@@ -117,14 +124,17 @@ __device__ __forceinline__ void bf_store(const StageRegs& t, __bf16* __restrict_
 //  16-lane group, lane 4q+p supplies the address of k row q, columns 4p..4p+3 and receives column (lane % 16), 4 k rows.
 //  EXEC must be all ones here (no divergence in the main loop).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int ROWS, int BKB>
 __device__ __forceinline__ bf16x8 bf_fetch(const __bf16* __restrict__ s, int kcontig, int rowbase, int ks, int lane) {
+  constexpr int BPITCH = BKB + 8;
+  constexpr int RP = ROWS + 8;
   if (kcontig) return *reinterpret_cast<const bf16x8*>(s + (rowbase + (lane & 31)) * BPITCH + ks * 16 + 8 * (lane >> 5));
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
   const int k0 = ks * 16 + 8 * (g >> 1);
-  const __bf16* a0 = s + (k0 + q) * BRPITCH + rowbase + 16 * (g & 1) + 4 * p;
+  const __bf16* a0 = s + (k0 + q) * RP + rowbase + 16 * (g & 1) + 4 * p;
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * BRPITCH));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * RP));
   union { s16x4 h[2]; bf16x8 v; } u;
   u.h[0] = lo;
   u.h[1] = hi;
@@ -138,9 +148,14 @@ __device__ __forceinline__ float bf_act_mask(float h, int act, bool keep, float 
   return scale;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) __bf16 As[BLDS];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[BLDS];
+// NT threads, ROWS x ROWS tile, waves WMW (along M) x WNW (along N), every wave (ROWS/WMW) x (ROWS/WNW) = MI x NI MFMA tiles
+template <bool ONES, int NT, int ROWS, int WMW, int WNW, int BKB>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const GemmBatch gb) {
+  constexpr int MI = ROWS / WMW / 32, NI = ROWS / WNW / 32;
+  constexpr int BPITCH = BKB + 8;
+  constexpr int LDSN = (ROWS * BPITCH > BKB * (ROWS + 8)) ? ROWS * BPITCH : BKB * (ROWS + 8);
+  __shared__ __attribute__((aligned(16))) __bf16 As[LDSN];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[LDSN];
   int pi = 0;
   while (pi + 1 < gb.n && (int)blockIdx.x >= gb.p[pi + 1].tile_start) ++pi;
   const GemmProblem& P = gb.p[pi];
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
   const int z = local % P.ksplit, t = local / P.ksplit;
   const int grp = t / (8 * P.tiles_n), within = t % (8 * P.tiles_n);
   const int rows_in_grp = min(8, P.tiles_m - grp * 8);
-  const int m0 = (grp * 8 + within % rows_in_grp) * BT, n0 = (within / rows_in_grp) * BT;
+  const int m0 = (grp * 8 + within % rows_in_grp) * ROWS, n0 = (within / rows_in_grp) * ROWS;
   const int kbeg = z * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
   const int a_kc = P.trans_a ? 0 : 1;
@@ -157,60 +172,61 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
   // block-uniform loader choice
   const bool a_al = (P.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(P.A) & 15) == 0;
   const bool b_al = (P.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(P.B) & 15) == 0;
-  const bool a_fast = a_al && (a_kc || m0 + BT <= P.M);
-  const bool b_fast = b_al && (b_kc || n0 + BT <= P.n_real);
+  const bool a_fast = a_al && (a_kc || m0 + ROWS <= P.M);
+  const bool b_fast = b_al && (b_kc || n0 + ROWS <= P.n_real);
   // virtual ones column of B (bias gradient = column sums of A over k): instead of a whole extra column tile for ONE column
   // (a third of the config-5 weight-gradient work), the first column tile's wn == 0 waves run one more MFMA per row tile
   // and k step against an all-ones operand; column 0 of that product is the column sum.
-  const bool ones_here = P.aug_ones && n0 == 0 && (threadIdx.x >> 7) == 0;  // wave-uniform
-
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm = w & 1, wn = w >> 1;
-  f32x16 acc[2][2];
+  const int wm = w % WMW, wn = w / WMW;
+  const bool ones_here = ONES && P.aug_ones && n0 == 0 && wn == 0;  // wave-uniform
+
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x16 acc1[2];
+  f32x16 acc1[ONES ? MI : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (ONES ? MI : 1); ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-  StageRegs ra, rb;
+  StageRegs<ROWS * BKB / 4 / NT> ra, rb;
   auto load = [&](int k0) {
-    if (a_fast) bf_load_fast(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
-    else bf_load_edge(ra, P.A, P.lda, a_kc, m0, P.M, P.M, 0, k0, kend);
-    if (b_fast) bf_load_fast(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
-    else bf_load_edge(rb, P.B, P.ldb, b_kc, n0, P.n_real, P.n_real, P.aug_ones, k0, kend);
+    if (a_fast) bf_load_fast<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
+    else bf_load_edge<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, P.M, 0, k0, kend);
+    if (b_fast) bf_load_fast<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
+    else bf_load_edge<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, P.n_real, P.aug_ones, k0, kend);
   };
   load(kbeg);
   for (int kt = kbeg; kt < kend; kt += BKB) {
-    bf_store(ra, As, a_kc);
-    bf_store(rb, Bs, b_kc);
+    bf_store<NT, ROWS, BKB>(ra, As, a_kc);
+    bf_store<NT, ROWS, BKB>(rb, Bs, b_kc);
     __syncthreads();
     if (kt + BKB < kend) load(kt + BKB);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 av[2], bv[2];
+    for (int ks = 0; ks < BKB / 16; ++ks) {
+      bf16x8 av[MI], bv[NI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        av[i] = bf_fetch(As, a_kc, wm * 64 + i * 32, ks, lane);
-        bv[i] = bf_fetch(Bs, b_kc, wn * 64 + i * 32, ks, lane);
-      }
+      for (int i = 0; i < MI; ++i) av[i] = bf_fetch<ROWS, BKB>(As, a_kc, wm * (MI * 32) + i * 32, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NI; ++j) bv[j] = bf_fetch<ROWS, BKB>(Bs, b_kc, wn * (NI * 32) + j * 32, ks, lane);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-      if (ones_here) {
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], ones, acc1[i], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      if constexpr (ONES) {
+        if (ones_here) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], ones, acc1[i], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -219,14 +235,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
   // D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   float* C = P.C + (int64_t)z * P.slab_stride;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
       if (col >= P.N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= P.M) continue;
         float v = acc[i][j][r];
         if (P.epi == EPI_ACTMASK) {
@@ -237,12 +253,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
         C[(int64_t)row * P.ldc + col] = v;
       }
     }
-  if (ones_here && (lane & 31) == 0) {  // column 0 of the ones product -> C[:, n_real]
+  if (ONES && ones_here && (lane & 31) == 0) {  // column 0 of the ones product -> C[:, n_real]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < (ONES ? MI : 1); ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < P.M) C[(int64_t)row * P.ldc + P.n_real] = acc1[i][r];
       }
   }
@@ -250,11 +266,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBatch gb) {
 
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
+  // 256x256 tiles when every problem is a plain (no split-K, no ones column) product with at least 4096 x 256 outputs
+  bool big = !want_split;
+  bool any_ones = false;
+  for (int i = 0; i < gb.n; ++i) {
+    const GemmProblem& p = gb.p[i];
+    HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_bf16: negative size");
+    any_ones = any_ones || p.aug_ones != 0;
+    if (p.aug_ones || p.M < 4096 || p.N < 192) big = false;
+  }
+  const int BT = big ? 256 : 128;
+  const int BKB = big ? 32 : 64;
   int start = 0, all_tiles = 0;
   for (int i = 0; i < gb.n; ++i) all_tiles += cdiv(gb.p[i].M, BT) * cdiv(gb.p[i].aug_ones ? (gb.p[i].n_real > 0 ? gb.p[i].n_real : 1) : gb.p[i].N, BT);
   for (int i = 0; i < gb.n; ++i) {
     GemmProblem& p = gb.p[i];
-    HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_bf16: negative size");
     p.tiles_m = cdiv(p.M, BT);
     p.tiles_n = cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, BT);  // the ones column rides in the first column tile
     const int tiles = p.tiles_m * p.tiles_n;
@@ -276,7 +302,9 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
   }
   gb.total_tiles = start;
   if (start == 0) return HMP_OK;
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(start), dim3(256), 0, st, gb);
+  if (big) hipLaunchKernelGGL((gemm_bf16_kernel<false, 512, 256, 4, 2, 32>), dim3(start), dim3(512), 0, st, gb);
+  else if (any_ones) hipLaunchKernelGGL((gemm_bf16_kernel<true, 256, 128, 2, 2, 64>), dim3(start), dim3(256), 0, st, gb);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, 256, 128, 2, 2, 64>), dim3(start), dim3(256), 0, st, gb);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

@@ -240,7 +240,8 @@ def test_dropout_mask_rate_and_determinism():
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(256, 256, 64, 0, 1), (1000, 300, 257, 0, 1), (513, 768, 256, 0, 0), (300, 257, 5000, 1, 0),
-                                         (128, 128, 32, 1, 1), (77, 130, 33, 0, 1)])
+                                         (128, 128, 32, 1, 1), (77, 130, 33, 0, 1),
+                                         (5000, 300, 260, 0, 1), (4200, 256, 768, 0, 0), (4100, 520, 96, 0, 1)])  # 256x256-tile variant
 def test_gemm_bf16_matches_bf16_rounded_inputs(M, N, K, ta, tb):
     """hmp_gemm_bf16 = fp32-accumulated product of the bf16-ROUNDED operands (round to nearest even): compared with exactly that
     in float64 (tolerance = fp32 accumulation of K terms), for every operand layout and ragged sizes (edge loaders)."""
