@@ -227,11 +227,11 @@ def test_front_kernel_odd_shapes():
 
 
 def test_bf16_compute_mode_on_a_large_graph():
-    """precision='bf16' only touches GEMM calls with >= 1024 64x64 tiles: a 24k-object graph with hidden 256 takes the bf16 path for
+    """precision='bf16' only touches GEMM calls with >= 1024 64x64 tiles: a 40k-object graph with hidden 256 takes the bf16 path for
     its projections; logits and loss stay within bf16 rounding of the fp32 engine, the fp32 mode is unchanged, small batches are
     bit-identical in both modes."""
     kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, dropout=0.0)
-    g = workloads.big_hetero_graph(n_obj=24000, n_rooms=240, seed=3).to(DEV)
+    g = workloads.big_hetero_graph(n_obj=40000, n_rooms=400, seed=3).to(DEV)  # >= 32768 nodes: the 256x256-tile weight-gradient path + colsum kernel
     _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
     net.eval()
     y = g["rooms"].y
