@@ -182,6 +182,7 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
     J.t_rowptr = wsi + F.t_rowptr; J.t_col = wsi + F.t_col; J.t_pos = nullptr;
     J.degf = reinterpret_cast<float*>(wsi + F.degf);
     J.cnt_in = J.cnt_out = J.cur_in = J.cur_out = nullptr;
+    J.tmpc_in = J.tmpc_out = nullptr;
     J.tmp_in = wsi + F.tmp_in; J.tmp_out = wsi + F.tmp_out; J.t_eid = wsi + F.t_eid; J.pos_of_eid = wsi + F.pos_of_eid;
     const bool last = pb + 1 == a.part_start[jd + 1];
     if (a.plan_rc) plan_small_part<true>(J, jd & 1, pb - a.part_start[jd], a.rows_per_part[jd], last, a.need_tpos, a.status, lds);

@@ -114,6 +114,7 @@ struct PlanJob {
   // scratch
   int *cnt_in, *cnt_out, *cur_in, *cur_out;  // must be zero on entry (one contiguous block); left zero on exit
   int *tmp_in, *tmp_out, *t_eid, *pos_of_eid;
+  int *tmpc_in, *tmpc_out;  // multi-launch build: the other endpoint of every scratch slot
 };
 struct PlanBatch {
   int n;

@@ -37,22 +37,63 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(const PlanBatch pb, int*
   }
 }
 
-// one 1024-thread block per (job, direction): exclusive scan of the counts
-__global__ __launch_bounds__(1024) void plan_scan_kernel(const PlanBatch pb) {
-  const int j = blockIdx.x >> 1, dir = blockIdx.x & 1;
-  const PlanJob& J = pb.j[j];
+// exclusive scan of the counts of every (job, direction) in three short launches over 4096-row segments (a single block
+// per (job, direction) took 1.06 ms for the 10^6-row types of config 5):
+//   partial  each segment's total  -> parked in ptr[segment start]
+//   tops     one block per (job, direction): exclusive scan of the parked totals (<= a few hundred), total -> ptr[n]
+//   final    each segment: local exclusive scan + its base -> rowptr
+constexpr int SCAN_SEG = 4096;
+struct ScanSegs {
+  int start[2 * HMP_MAX_EDGE_TYPES + 1];  // first block of (job, dir)
+};
+
+__device__ __forceinline__ int block_sum_1024(int v, int* wsum) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) wsum[w] = v;
+  __syncthreads();
+  int t = 0;
+  for (int q = 0; q < 16; ++q) t += wsum[q];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void plan_scan_partial_kernel(const PlanBatch pb, const ScanSegs sg) {
+  __shared__ int wsum[16];
+  int jd = 0;
+  while (jd + 1 < 2 * pb.n && (int)blockIdx.x >= sg.start[jd + 1]) ++jd;
+  const PlanJob& J = pb.j[jd >> 1];
+  const int dir = jd & 1;
   const int n = dir ? J.n_src : J.n_dst;
   const int* cnt = dir ? J.cnt_out : J.cnt_in;
   int* ptr = dir ? J.t_rowptr : J.rowptr;
+  const int base = ((int)blockIdx.x - sg.start[jd]) * SCAN_SEG;
+  int v = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = base + threadIdx.x + j * 1024;
+    if (i < n) v += cnt[i];
+  }
+  const int t = block_sum_1024(v, wsum);
+  if (threadIdx.x == 0) ptr[base] = t;
+}
+
+__global__ __launch_bounds__(1024) void plan_scan_tops_kernel(const PlanBatch pb) {
+  const int j = blockIdx.x >> 1, dir = blockIdx.x & 1;
+  const PlanJob& J = pb.j[j];
+  const int n = dir ? J.n_src : J.n_dst;
+  int* ptr = dir ? J.t_rowptr : J.rowptr;
+  const int nseg = (n + SCAN_SEG - 1) / SCAN_SEG;
   __shared__ int wsum[16];
   __shared__ int carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n ? cnt[i] : 0;
-    int x = v;  // inclusive scan inside the wave
+  for (int b0 = 0; b0 < nseg; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < nseg ? ptr[(int64_t)i * SCAN_SEG] : 0;
+    int x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(x, o);
@@ -63,12 +104,47 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const PlanBatch pb) {
     int woff = 0;
     for (int q = 0; q < w; ++q) woff += wsum[q];
     const int carry = carry_s;
-    if (i < n) ptr[i] = carry + woff + x - v;
+    if (i < nseg) ptr[(int64_t)i * SCAN_SEG] = carry + woff + x - v;
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = carry + woff + x;
     __syncthreads();
   }
   if (threadIdx.x == 0) ptr[n] = carry_s;
+}
+
+__global__ __launch_bounds__(1024) void plan_scan_final_kernel(const PlanBatch pb, const ScanSegs sg) {
+  __shared__ int wsum[16];
+  int jd = 0;
+  while (jd + 1 < 2 * pb.n && (int)blockIdx.x >= sg.start[jd + 1]) ++jd;
+  const PlanJob& J = pb.j[jd >> 1];
+  const int dir = jd & 1;
+  const int n = dir ? J.n_src : J.n_dst;
+  const int* cnt = dir ? J.cnt_out : J.cnt_in;
+  int* ptr = dir ? J.t_rowptr : J.rowptr;
+  const int base = ((int)blockIdx.x - sg.start[jd]) * SCAN_SEG;
+  const int segbase = ptr[base];  // parked by the tops kernel; row `base` itself gets exactly this value back
+  const int r0 = base + 4 * (int)threadIdx.x;
+  int c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = (r0 + j < n) ? cnt[r0 + j] : 0;
+  const int s4 = c[0] + c[1] + c[2] + c[3];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = s4;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();  // also orders every thread's read of ptr[base] before thread 0 rewrites it
+  int woff = 0;
+  for (int q = 0; q < w; ++q) woff += wsum[q];
+  int run = segbase + woff + x - s4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (r0 + j < n) ptr[r0 + j] = run;
+    run += c[j];
+  }
 }
 
 __global__ __launch_bounds__(256) void plan_fill_kernel(const PlanBatch pb) {
@@ -81,8 +157,10 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const PlanBatch pb) {
     if (s < 0 || s >= J.n_src || d < 0 || d >= J.n_dst) continue;
     const int pi = atomicAdd(&J.cur_in[d], 1);
     J.tmp_in[J.rowptr[d] + pi] = (int)e;
+    J.tmpc_in[J.rowptr[d] + pi] = (int)s;  // the other endpoint travels with the edge id: no random re-read of ei in the rank pass
     const int po = atomicAdd(&J.cur_out[s], 1);
     J.tmp_out[J.t_rowptr[s] + po] = (int)e;
+    J.tmpc_out[J.t_rowptr[s] + po] = (int)d;
   }
 }
 
@@ -99,6 +177,7 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
     const int row = (int)(r - pb.row_start[jd]);
     const int* ptr = dir ? J.t_rowptr : J.rowptr;
     const int* tmp = dir ? J.tmp_out : J.tmp_in;
+    const int* tmpc = dir ? J.tmpc_out : J.tmpc_in;
     const int b = ptr[row], deg = ptr[row + 1] - b;
     if (lane == 0) {
       // this wave is the last reader of the row's counters: leave them zero for the next build
@@ -112,11 +191,11 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
       const int pos = b + rank;
       if (dir == 0) {
         J.eid[pos] = mine;
-        J.col[pos] = (int)J.ei[mine];  // source endpoint
+        J.col[pos] = tmpc[b + c];  // source endpoint
         J.pos_of_eid[mine] = pos;
       } else {
         J.t_eid[pos] = mine;
-        J.t_col[pos] = (int)J.ei[J.E + mine];  // destination endpoint
+        J.t_col[pos] = tmpc[b + c];  // destination endpoint
       }
     }
   }
@@ -142,9 +221,9 @@ __global__ __launch_bounds__(1024) void plan_small_kernel(const PlanSmallArgs a,
 }
 
 size_t plan_scratch_ints(int64_t E, int n_src, int n_dst) {
-  // cnt_in, cur_in [n_dst]; cnt_out, cur_out [n_src]; tmp_in, tmp_out, t_eid, pos_of_eid [E]; each 64-int aligned
+  // cnt_in, cur_in [n_dst]; cnt_out, cur_out [n_src]; tmp_in, tmp_out, t_eid, pos_of_eid, tmpc_in, tmpc_out [E]; each 64-int aligned
   auto a = [](int64_t x) { return (size_t)((x + 63) & ~(int64_t)63); };
-  return 2 * a(n_dst) + 2 * a(n_src) + 4 * a(E);
+  return 2 * a(n_dst) + 2 * a(n_src) + 6 * a(E);
 }
 
 void plan_carve(PlanJob& job, int* s) {
@@ -156,7 +235,9 @@ void plan_carve(PlanJob& job, int* s) {
   job.tmp_in = s;  s += a(job.E);
   job.tmp_out = s; s += a(job.E);
   job.t_eid = s;   s += a(job.E);
-  job.pos_of_eid = s;
+  job.pos_of_eid = s; s += a(job.E);
+  job.tmpc_in = s; s += a(job.E);
+  job.tmpc_out = s;
 }
 
 int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
@@ -198,8 +279,20 @@ int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
     hipLaunchKernelGGL(plan_hist_kernel, dim3(eg), dim3(256), 0, st, pb, d_status);
     HMP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(2 * pb.n), dim3(1024), 0, st, pb);
-  HMP_LAUNCH_CHECK();
+  {
+    ScanSegs sg;
+    int blocks = 0;
+    for (int jd = 0; jd < 2 * pb.n; ++jd) {
+      const int nrows = (jd & 1) ? pb.j[jd >> 1].n_src : pb.j[jd >> 1].n_dst;
+      sg.start[jd] = blocks;
+      blocks += cdiv(nrows, SCAN_SEG);
+    }
+    sg.start[2 * pb.n] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(plan_scan_partial_kernel, dim3(blocks), dim3(1024), 0, st, pb, sg);
+    hipLaunchKernelGGL(plan_scan_tops_kernel, dim3(2 * pb.n), dim3(1024), 0, st, pb);
+    if (blocks > 0) hipLaunchKernelGGL(plan_scan_final_kernel, dim3(blocks), dim3(1024), 0, st, pb, sg);
+    HMP_LAUNCH_CHECK();
+  }
   if (E > 0) {
     hipLaunchKernelGGL(plan_fill_kernel, dim3(eg), dim3(256), 0, st, pb);
     HMP_LAUNCH_CHECK();

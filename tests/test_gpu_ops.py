@@ -53,7 +53,7 @@ def rand_edges(rng, E, n_src, n_dst):
 
 
 @pytest.mark.parametrize("E,n_src,n_dst", [(0, 3, 4), (1, 1, 1), (17, 5, 3), (482, 62, 62), (20000, 700, 90), (5000, 1, 4000), (3000, 2000, 1),
-                                          (60000, 2500, 3100), (100000, 3000, 2500)])
+                                          (60000, 2500, 3100), (100000, 3000, 2500), (200000, 9000, 12345), (70000, 8192, 4096)])
 def test_plan_bit_exact(E, n_src, n_dst):
     rng = np.random.default_rng(E + n_src)
     ei = rand_edges(rng, E, n_src, n_dst)
