@@ -265,13 +265,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # host cost of a step = time to ENQUEUE a few steps from an idle stream (no queue back-pressure); untimed extra steps
+    host_us, extra_steps = 1e9, 0
+    for _ in range(3):  # best of 3: the first launches after an idle period pay a wake-up that is not host work
+        sync_all()
+        th = time.perf_counter()
+        for _ in range(10):
+            step(batch, labels)
+        host_us = min(host_us, 1e5 * (time.perf_counter() - th))
+        extra_steps += 10
     sync_all()
-    th = time.perf_counter()
-    for _ in range(10):
-        step(batch, labels)
-    host_us = 1e5 * (time.perf_counter() - th)
-    sync_all()
-    extra_steps = 10
     final_loss = step.loss()
     nstep, status = net.native().read_state()
     assert status == 0, f"engine status bits {status}"
