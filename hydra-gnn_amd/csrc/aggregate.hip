@@ -338,6 +338,8 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
 // for both operands (k = 16 i + 4 kq + u at step u), which a sum over k does not care about.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// (32-row tiles -- half the per-row weight traffic, two MFMA row halves sharing each B load -- were measured SLOWER on the
+// H-tree config 4: 0.585 against 0.474 ms/step; half as many blocks, twice the gather passes per block.)
 template <int GS>
 __global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
   constexpr int TM = 16, LDH = 17;
