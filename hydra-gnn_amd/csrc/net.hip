@@ -78,11 +78,9 @@ struct hmp_net {
 
   // static device tables (owned)
   PackSeg* d_pack_segs = nullptr;
-  int64_t* d_pack_row_start = nullptr;
   int n_pack = 0;
   int64_t pack_rows = 0;
   GradSeg* d_grad_segs = nullptr;
-  int64_t* d_grad_elem_start = nullptr;
   int n_grad = 0;
   int64_t grad_elems = 0;
   int max_pack_rows = 0;
@@ -463,13 +461,9 @@ int build_tables(hmp_net* n) {
     n->grad_sb.start[i + 1] = n->grad_sb.start[i] + cdiv(el, wave_mode ? 4 : 256);
   }
   HMP_HIP(hipMalloc(&n->d_pack_segs, ps.size() * sizeof(PackSeg)));
-  HMP_HIP(hipMalloc(&n->d_pack_row_start, prs.size() * sizeof(int64_t)));
   HMP_HIP(hipMalloc(&n->d_grad_segs, gs.size() * sizeof(GradSeg)));
-  HMP_HIP(hipMalloc(&n->d_grad_elem_start, ges.size() * sizeof(int64_t)));
   HMP_HIP(hipMemcpy(n->d_pack_segs, ps.data(), ps.size() * sizeof(PackSeg), hipMemcpyHostToDevice));
-  HMP_HIP(hipMemcpy(n->d_pack_row_start, prs.data(), prs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   HMP_HIP(hipMemcpy(n->d_grad_segs, gs.data(), gs.size() * sizeof(GradSeg), hipMemcpyHostToDevice));
-  HMP_HIP(hipMemcpy(n->d_grad_elem_start, ges.data(), ges.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   for (int l = 0; l < n->L; ++l)
     if (n->lay[l].kind == HMP_CONV_GAT) HMP_HIP(hipMalloc(&n->lay[l].d_gat, sizeof(GatLayerS)));
   return HMP_OK;
@@ -1262,10 +1256,8 @@ extern "C" void hmp_net_destroy(hmp_net* n) {
   for (int i = 0; i < 2; ++i)
     if (n->side[i]) (void)hipStreamDestroy(n->side[i]);
   if (n->d_pack_segs) (void)hipFree(n->d_pack_segs);
-  if (n->d_pack_row_start) (void)hipFree(n->d_pack_row_start);
   if (n->d_pack_map) (void)hipFree(n->d_pack_map);
   if (n->d_grad_segs) (void)hipFree(n->d_grad_segs);
-  if (n->d_grad_elem_start) (void)hipFree(n->d_grad_elem_start);
   for (int l = 0; l < HMP_MAX_LAYERS; ++l)
     if (l < n->L && n->lay[l].d_gat) (void)hipFree(n->lay[l].d_gat);
   delete n;
