@@ -392,7 +392,7 @@ def main():
                     out["roofline"]["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
 
     # ---- CPU baseline: the oracle (op-for-op PyG restatement) on the host cores, bounded sample -------------------------
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (the contract): other ranks would idle at the barrier
         from oracle import models as omodels
 
         # the GPU box gives one-GPU jobs a 16-CPU share; more intra-op threads than that only oversubscribes
