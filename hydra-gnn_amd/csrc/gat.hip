@@ -23,6 +23,8 @@
 
 namespace hmp {
 
+KT_DEFINE(gat)
+
 namespace {
 
 constexpr float NEG_SLOPE = 0.2f;
@@ -299,6 +301,8 @@ __device__ __forceinline__ void load_g(const GatDstS& D, const GatDyn& dyn, int 
 
 template <int HM, int GS>
 __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restrict__ tab, const GatDyn dyn) {
+  constexpr int CAP = 16;  // edges per row whose sweep-0 scalars are parked in LDS (multiple of the batch size)
+  __shared__ float cache[256 / GS][CAP][HM][4];
   int di = 0;
   while (di + 1 < tab->n_dst && (int)blockIdx.x >= dyn.block_start[di + 1]) ++di;
   const GatDstS& D = tab->d[di];
@@ -309,9 +313,11 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
   const bool cact = c0 < D.Cp;
   const int H = D.H;
   float4 g[HM];
+  KT(0);
   load_g<HM>(D, dyn, row, c0, cact, g);
 
   for (int ii = 0; ii < D.n_in; ++ii) {
+    KT(1 + 4 * ii);
     const GatInS& I = D.in[ii];
     const int64_t E = dyn.n_edges[I.et];
     const int n_loop = I.self_loops ? min(dyn.n_nodes[I.src_t], dyn.n_nodes[D.t]) : 0;
@@ -335,54 +341,126 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
 
     constexpr int UB = (HM <= 4) ? 4 : 2;
     const int cc = cact ? c0 : 0;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      for (int k0 = b; k0 < kend; k0 += UB) {
-        EdgeBatch<HM, UB> B;
-        fetch_batch<HM, UB>(I, D.Cp, ea, H, row, b, e, kend, k0, cc, ad, ve, B);
+    // Sweep 0 needs every neighbour row (d alpha' = <g, h_s[j]>) to form sum_k alpha_k d alpha_k; sweep 1 needs only the
+    // per-(edge, head) scalars again.  The first CAP edges of a row park them in LDS {alpha, d alpha, leaky slope, dropout
+    // scale} (alpha < 0 marks a removed self loop), so sweep 1 re-reads NO neighbour rows for them: one lane per edge
+    // finishes d logit and stores it.  Edges past CAP take the old path (fetch + recompute).
+    float (*crow)[HM][4] = cache[threadIdx.x / GS];
+    const int n_all = kend - b;
+    const int n_cached = n_all < CAP ? n_all : CAP;
+    KT(2 + 4 * ii);
+    for (int k0 = b; k0 < kend; k0 += UB) {  // ---- sweep 0
+      EdgeBatch<HM, UB> B;
+      fetch_batch<HM, UB>(I, D.Cp, ea, H, row, b, e, kend, k0, cc, ad, ve, B);
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int k = k0 + u;
-          const int64_t pos = B.loop[u] ? (E + row) : (int64_t)k;
-          if (B.removed[u]) {  // removed self loop: contributes nothing
-            if (sweep == 1 && gl == 0) {
+      for (int u = 0; u < UB; ++u) {
+        const int k = k0 + u;
+        const int idx = k - b;
+        if (B.removed[u]) {
+          if (gl == 0 && idx < CAP) {
 #pragma unroll
-              for (int h = 0; h < HM; ++h)
-                if (h < H) {
-                  I.alpha_drop[pos * GAT_HMAX + h] = 0.f;
-                  I.dlogit[pos * GAT_HMAX + h] = 0.f;
-                  if (I.dlogit_orig) I.dlogit_orig[(int64_t)I.eid[k] * GAT_HMAX + h] = 0.f;
-                }
-            }
-            continue;
+            for (int h = 0; h < HM; ++h) crow[idx][h][0] = -1.f;
           }
-          if (!B.live[u]) continue;
-          bool keep[HM];
+          continue;
+        }
+        if (!B.live[u]) continue;
+        const int64_t pos = B.loop[u] ? (E + row) : (int64_t)k;
+        bool keep[HM];
 #pragma unroll
-          for (int h = 0; h < HM; ++h) keep[h] = true;
-          if (adrop) alpha_keep<HM>(acfg, pos, keep);
+        for (int h = 0; h < HM; ++h) keep[h] = true;
+        if (adrop) alpha_keep<HM>(acfg, pos, keep);
 #pragma unroll
-          for (int h = 0; h < HM; ++h) {
-            if (h >= H) continue;
-            float part = 0.f;
-            if (cact) part = dot4(g[h], B.v[u][h]);
-            const float dap = group_sum<GS>(part);  // d alpha'_k,h (identical in every lane of the group)
-            const float rw = B.raw[u][h];
-            const float ev = rw > 0.f ? rw : NEG_SLOPE * rw;
-            const float alpha = expf(ev - m[h]) / den[h];
-            const float dscale = adrop ? (keep[h] ? acfg.scale : 0.f) : 1.f;
-            const float da = dap * dscale;
-            if (sweep == 0) {
-              tsum[h] += alpha * da;
-            } else {
-              const float de = alpha * (da - tsum[h]);
-              const float dl = de * (rw > 0.f ? 1.f : NEG_SLOPE);
-              dsum[h] += dl;
-              if (gl == 0) {
-                I.alpha_drop[pos * GAT_HMAX + h] = alpha * dscale;
-                I.dlogit[pos * GAT_HMAX + h] = dl;
-                if (I.dlogit_orig && !B.loop[u]) I.dlogit_orig[(int64_t)B.eid[u] * GAT_HMAX + h] = dl;
+        for (int h = 0; h < HM; ++h) {
+          if (h >= H) continue;
+          float part = 0.f;
+          if (cact) part = dot4(g[h], B.v[u][h]);
+          const float dap = group_sum<GS>(part);  // d alpha'_k,h (identical in every lane of the group)
+          const float rw = B.raw[u][h];
+          const float ev = rw > 0.f ? rw : NEG_SLOPE * rw;
+          const float alpha = expf(ev - m[h]) / den[h];
+          const float dscale = adrop ? (keep[h] ? acfg.scale : 0.f) : 1.f;
+          const float da = dap * dscale;
+          tsum[h] += alpha * da;
+          if (gl == 0 && idx < CAP) {
+            crow[idx][h][0] = alpha; crow[idx][h][1] = da; crow[idx][h][2] = (rw > 0.f ? 1.f : NEG_SLOPE); crow[idx][h][3] = dscale;
+          }
+        }
+      }
+    }
+    // writer (lane 0 of the group) and readers share a wavefront: order the LDS traffic, no block barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    KT(3 + 4 * ii);
+    {  // ---- sweep 1, cached edges: lane gl takes edges gl, gl + GS, ...
+      float dpart[HM];
+#pragma unroll
+      for (int h = 0; h < HM; ++h) dpart[h] = 0.f;
+      for (int idx = gl; idx < n_cached; idx += GS) {
+        const int k = b + idx;
+        const bool is_loop = k >= e;
+        const int64_t pos = is_loop ? (E + row) : (int64_t)k;
+        const int eo = (I.dlogit_orig && !is_loop) ? I.eid[k] : 0;
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+          if (h >= H) continue;
+          const float alpha = crow[idx][h][0];
+          float apd = 0.f, dl = 0.f;
+          if (alpha >= 0.f) {
+            const float de = alpha * (crow[idx][h][1] - tsum[h]);
+            dl = de * crow[idx][h][2];
+            apd = alpha * crow[idx][h][3];
+            dpart[h] += dl;
+          }
+          I.alpha_drop[pos * GAT_HMAX + h] = apd;
+          I.dlogit[pos * GAT_HMAX + h] = dl;
+          if (I.dlogit_orig && !is_loop) I.dlogit_orig[(int64_t)eo * GAT_HMAX + h] = dl;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < HM; ++h) dsum[h] = group_sum<GS>(dpart[h]);
+    }
+    for (int k0 = b + CAP; k0 < kend; k0 += UB) {  // ---- sweep 1, edges past the cache: recompute
+      EdgeBatch<HM, UB> B;
+      fetch_batch<HM, UB>(I, D.Cp, ea, H, row, b, e, kend, k0, cc, ad, ve, B);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int k = k0 + u;
+        const int64_t pos = B.loop[u] ? (E + row) : (int64_t)k;
+        if (B.removed[u]) {  // removed self loop: contributes nothing
+          if (gl == 0) {
+#pragma unroll
+            for (int h = 0; h < HM; ++h)
+              if (h < H) {
+                I.alpha_drop[pos * GAT_HMAX + h] = 0.f;
+                I.dlogit[pos * GAT_HMAX + h] = 0.f;
+                if (I.dlogit_orig) I.dlogit_orig[(int64_t)I.eid[k] * GAT_HMAX + h] = 0.f;
               }
-            }
+          }
+          continue;
+        }
+        if (!B.live[u]) continue;
+        bool keep[HM];
+#pragma unroll
+        for (int h = 0; h < HM; ++h) keep[h] = true;
+        if (adrop) alpha_keep<HM>(acfg, pos, keep);
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+          if (h >= H) continue;
+          float part = 0.f;
+          if (cact) part = dot4(g[h], B.v[u][h]);
+          const float dap = group_sum<GS>(part);
+          const float rw = B.raw[u][h];
+          const float ev = rw > 0.f ? rw : NEG_SLOPE * rw;
+          const float alpha = expf(ev - m[h]) / den[h];
+          const float dscale = adrop ? (keep[h] ? acfg.scale : 0.f) : 1.f;
+          const float da = dap * dscale;
+          const float de = alpha * (da - tsum[h]);
+          const float dl = de * (rw > 0.f ? 1.f : NEG_SLOPE);
+          dsum[h] += dl;
+          if (gl == 0) {
+            I.alpha_drop[pos * GAT_HMAX + h] = alpha * dscale;
+            I.dlogit[pos * GAT_HMAX + h] = dl;
+            if (I.dlogit_orig && !B.loop[u]) I.dlogit_orig[(int64_t)B.eid[u] * GAT_HMAX + h] = dl;
           }
         }
       }
@@ -392,6 +470,7 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
       for (int h = 0; h < HM; ++h)
         if (h < H) I.dz_dst[(int64_t)row * I.lddz_dst + I.adoff + h] = dsum[h];
     }
+    KT(4 + 4 * ii);
   }
 }
 
