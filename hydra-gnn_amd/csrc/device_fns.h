@@ -20,13 +20,40 @@ __device__ __forceinline__ void pack_item(const PackSeg& S, int item, const floa
     const int h = r / S.Cp, cc = r % S.Cp;
     if (h < S.H && cc < S.C && c < S.cols) v = params[S.src[0] + (int64_t)(h * S.C + cc) * S.ld_src + c];
   } else if (S.kind == PACK_ATTDOT) {  // row r = head
-    if (r < S.H && c < S.cols)
-      for (int cc = 0; cc < S.C; ++cc)
-        v += params[S.att + r * S.C + cc] * params[S.src[0] + (int64_t)(r * S.C + cc) * S.ld_src + c];
+    if (r < S.H && c < S.cols) {
+      // C-long dot product; 8 terms' loads in flight at a time (clamped), added in index order
+      const float* av = params + S.att + r * S.C;
+      const float* wv = params + S.src[0] + (int64_t)(r * S.C) * S.ld_src + c;
+      for (int cc = 0; cc < S.C; cc += 8) {
+        float a8[8], w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ci = min(cc + u, S.C - 1);
+          a8[u] = av[ci];
+          w8[u] = wv[(int64_t)ci * S.ld_src];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (cc + u < S.C) v += a8[u] * w8[u];
+      }
+    }
   } else {  // PACK_ATTDOT_T: row r = edge-attribute dimension d, column c = head
-    if (r < S.rows && c < S.H)
-      for (int cc = 0; cc < S.C; ++cc)
-        v += params[S.att + c * S.C + cc] * params[S.src[0] + (int64_t)(c * S.C + cc) * S.ld_src + r];
+    if (r < S.rows && c < S.H) {
+      const float* av = params + S.att + c * S.C;
+      const float* wv = params + S.src[0] + (int64_t)(c * S.C) * S.ld_src + r;
+      for (int cc = 0; cc < S.C; cc += 8) {
+        float a8[8], w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ci = min(cc + u, S.C - 1);
+          a8[u] = av[ci];
+          w8[u] = wv[(int64_t)ci * S.ld_src];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (cc + u < S.C) v += a8[u] * w8[u];
+      }
+    }
   }
   dst[c] = v;
 }
