@@ -168,6 +168,21 @@ int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_param
 // grid = (element chunks of 1024, segments).  Block (0,0) additionally sums the per-row {loss, valid} pairs of the
 // loss kernel in fixed order into out2 = {loss_sum, count} (the tail of the flat gradient buffer).
 // ---------------------------------------------------------------------------------------------
+// sum over the split-K slabs of one element, slab 0 first; 8 (clamped) loads in flight per trip instead of one dependent
+// load per slab
+__device__ __forceinline__ float slab_sum(const float* __restrict__ src, int ns, int64_t stride) {
+  float v = 0.f;
+  for (int z0 = 0; z0 < ns; z0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)min(z0 + u, ns - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z0 + u < ns) v += t[u];
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restrict__ segs, const SegBlocks sb, const GradReduceDyn dyn,
                                                           const float* __restrict__ slabs, const float* params,
                                                           float* __restrict__ grads, const float* __restrict__ row_lv, int n_lv_rows,
@@ -188,18 +203,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
       float part = 0.f;
       if (T.kind == GT_ATT_DOT) {
         const float* src = slabs + T.src + (int64_t)(r / T.C) * T.ld;
-        for (int f = lane; f < T.inner; f += 64) {
-          float s = 0.f;
-          for (int z = 0; z < ns; ++z) s += src[z * stride + f];
-          part += s * w[f];
-        }
+        for (int f = lane; f < T.inner; f += 64) part += slab_sum(src + f, ns, stride) * w[f];
       } else {
         const float* base = slabs + T.src + (r / T.C);
-        for (int d = lane; d < T.inner; d += 64) {
-          float s = 0.f;
-          for (int z = 0; z < ns; ++z) s += base[z * stride + (int64_t)d * T.ld];
-          part += s * w[d];
-        }
+        for (int d = lane; d < T.inner; d += 64) part += slab_sum(base + (int64_t)d * T.ld, ns, stride) * w[d];
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -217,13 +224,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
       const float* base = slabs + T.src;
       float v = 0.f;
       if (T.kind == GT_COPY) {
-        const float* src = base + (int64_t)((r / T.C) * T.Cp + (r % T.C)) * T.ld + c;
-        for (int z = 0; z < ns; ++z) v += src[z * stride];
+        v = slab_sum(base + (int64_t)((r / T.C) * T.Cp + (r % T.C)) * T.ld + c, ns, stride);
       } else if (T.kind == GT_ATT_OUTER) {
-        const float* src = base + (int64_t)(r / T.C) * T.ld + c;
-        float s = 0.f;
-        for (int z = 0; z < ns; ++z) s += src[z * stride];
-        v = params[T.att + r] * s;
+        v = params[T.att + r] * slab_sum(base + (int64_t)(r / T.C) * T.ld + c, ns, stride);
       } else if (T.kind == GT_ATT_DOT) {
         const float* src = base + (int64_t)(r / T.C) * T.ld;
         const float* w = params + T.w + (int64_t)r * T.ldw;
@@ -233,10 +236,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
           v += s * w[f];
         }
       } else if (T.kind == GT_ATT_OUTER_T) {
-        const float* src = base + (int64_t)c * T.ld + (r / T.C);
-        float s = 0.f;
-        for (int z = 0; z < ns; ++z) s += src[z * stride];
-        v = params[T.att + r] * s;
+        v = params[T.att + r] * slab_sum(base + (int64_t)c * T.ld + (r / T.C), ns, stride);
       } else {  // GT_ATT_DOT_T
         const float* w = params + T.w + (int64_t)r * T.ldw;
         for (int d = 0; d < T.inner; ++d) {
