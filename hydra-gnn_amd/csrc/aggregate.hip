@@ -271,7 +271,7 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
 // with mask = label != ignored; writes the gradient of the SUM loss and the row's {loss, valid} pair.  The group
 // reductions are xor butterflies below GS, i.e. inside the (GS-aligned) row group.
 template <int GS>
-__device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, int row, int c0, Acc<4>& t) {
+__device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, int row, int c0, Acc<4>& t, int64_t y) {
   const int nc = D.ce_classes;
   float v[4];
   bool in[4];
@@ -290,7 +290,6 @@ __device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, in
 #pragma unroll
   for (int o = GS / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float lse = m + logf(s);
-  const int64_t y = D.ce_labels[row];
   const bool valid = (y != D.ce_ignored);
   const bool bad = valid && (y < 0 || y >= nc);
   const bool use = valid && !bad;
@@ -322,9 +321,12 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   if (row >= D.n_rows) return;
   Acc<4> tot[NV];
   const int c0 = (threadIdx.x % GS) * 4;
+  // the label is requested before the aggregation (it depends on nothing): one round trip less behind the last gather
+  int64_t y = 0;
+  if (NV == 1 && D.ce_labels) y = D.ce_labels[row];
   agg_row<GS, NV>(D, a.mean, row, c0, tot);
   if constexpr (NV == 1) {
-    if (D.ce_labels) ce_rowgroup<GS>(D, a.state, row, c0, tot[0]);
+    if (D.ce_labels) ce_rowgroup<GS>(D, a.state, row, c0, tot[0], y);
   }
 }
 
@@ -653,6 +655,13 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     const float* wp = S.xw + min(col, S.xN - 1) + (int64_t)kq * S.xldw;  // clamped: padded columns are never stored
     const float* hp = Hs + kq * LDH + nn;                                  // A operand: row m = lane & 15 of the tile
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // activations whose derivative masks this tile's output: requested before the weight loads / MFMA chain instead of after
+    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (S.xh) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        hv[r] = S.xh[(int64_t)min(row0 + kq * 4 + r, S.n_rows - 1) * S.xldh + min(col, S.xN - 1)];
+    }
     // 48 k-steps (192 stacked columns) per trip: the (clamped) weight loads are all in flight together, then the MFMA
     // chain runs -- one L2 round trip for the typical stacked width.  (Requesting them before the gather was measured
     // SLOWER, +1 us: 48 scalar loads per lane queue in front of the gather's own loads.)
@@ -672,7 +681,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
         if (row >= S.n_rows) continue;
         float v = acc[r];
         if (S.xh) {
-          const float h = S.xh[(int64_t)row * S.xldh + col];
+          const float h = hv[r];
           // dropped elements were stored as -0.0f by the forward: the keep bit is the sign of a zero
           const bool keep = !S.xdrop_on || (__float_as_uint(h) != 0x80000000u);
           float f = S.xscale;

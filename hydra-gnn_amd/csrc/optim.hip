@@ -216,6 +216,14 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
     const int64_t i = (int64_t)((int)blockIdx.x - sb.start[si]) * 256 + threadIdx.x;
     if (i < n_el) {
     const int r = (int)(i / S.cols), c = (int)(i % S.cols);
+    // Adam state of this element, requested before the slab sums so that it travels with them (adam.on is kernel-uniform)
+    float a_p = 0.f, a_m = 0.f, a_v = 0.f, a_cnt = 1.f;
+    int a_t = 1;
+    if (adam.on) {
+      a_p = adam.p[S.dst + i]; a_m = adam.m[S.dst + i]; a_v = adam.v[S.dst + i];
+      a_cnt = *adam.count;
+      a_t = *adam.step_dev;
+    }
     float total = 0.f;
     for (int ti = 0; ti < S.n_terms; ++ti) {
       const GradTerm& T = S.t[ti];
@@ -251,16 +259,16 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradSeg* __restr
     if (adam.on) {
       // torch.optim.Adam with coupled L2 on this element (same arithmetic as adam_kernel); only taken when no gradient
       // term of the network reads parameters (SAGE), so updating in place cannot race with another thread's reads
-      const int t = *adam.step_dev;
+      const int t = a_t;
       const float bc1 = 1.f - powf(adam.b1, (float)t);
       const float bc2 = 1.f - powf(adam.b2, (float)t);
-      const float c = *adam.count;
+      const float c = a_cnt;
       const float gscale = 1.f / (c > 1.f ? c : 1.f);
       const int64_t e = S.dst + i;
-      const float pi = adam.p[e];
+      const float pi = a_p;
       const float gi = total * gscale + adam.wd * pi;
-      const float mi = adam.b1 * adam.m[e] + (1.f - adam.b1) * gi;
-      const float vi = adam.b2 * adam.v[e] + (1.f - adam.b2) * gi * gi;
+      const float mi = adam.b1 * a_m + (1.f - adam.b1) * gi;
+      const float vi = adam.b2 * a_v + (1.f - adam.b2) * gi * gi;
       adam.m[e] = mi;
       adam.v[e] = vi;
       const float denom = sqrtf(vi) / sqrtf(bc2) + adam.eps;
