@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
 template <int GS, int NV>
 __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int c0, Acc<4> (&tot)[NV]) {
   constexpr int VEC = 4;
+  // dropout coordinates incl. the device step counter: read now, not behind the gathers (one dependent round trip less)
+  DropCfg dcfg = D.drop;
+  if (D.drop_on) dcfg = drop_resolve(D.drop);
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c = c0 + q * GS * VEC;
@@ -252,7 +255,7 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
     const int c = c0 + q * GS * VEC;
     if (c >= D.F) continue;
     bool keep[4] = {true, true, true, true};
-    if (D.drop_on) drop_keep4(drop_resolve(D.drop), (uint32_t)row * (uint32_t)(D.ldo >> 2) + (uint32_t)(c >> 2), keep);
+    if (D.drop_on) drop_keep4(dcfg, (uint32_t)row * (uint32_t)(D.ldo >> 2) + (uint32_t)(c >> 2), keep);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v = tot[q].at(i);
