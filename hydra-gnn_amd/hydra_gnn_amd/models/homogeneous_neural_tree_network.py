@@ -1,16 +1,19 @@
 """``HomogeneousNeuralTreeNetwork`` -- drop-in for the reference's
-``src/hydra_gnn/models/homogeneous_neural_tree_network.py:7-109`` (GraphSAGE / GAT / GAT_edge branches) on the MI355X
-engine.
+``src/hydra_gnn/models/homogeneous_neural_tree_network.py:7-109`` on the MI355X engine.
 
 One node type, three edge types of ONE native program: ``pre_mp`` (a 1-head GAT over ``init_edge_index`` without self
 loops; the reference applies it to EVERY node, so nodes without an incoming initialisation edge end up with the bias
 alone, :83-84), the message passing layers over ``edge_index``, and ``LeafPool`` (mean over ``pool_edge_index``, the
 executor's pool stage).  The readout ``x[room_mask]`` stays in torch.
+
+GCN / GIN (``htree_GCN.yaml`` / ``htree_GIN.yaml``): ``pre_mp`` runs as a one-layer native program, the convolutions and
+``LeafPool`` op by op (:mod:`hydra_gnn_amd.ops`); as in the reference, this class's loop never applies ``batch_norms``.
 """
 from __future__ import annotations
 
 import torch.nn as nn
 
+from .. import ops
 from ..engine import LayerDesc, NativeNet
 from .._lib import ACT_NONE
 from .heterogeneous_neural_tree_network import LeafPool
@@ -50,6 +53,25 @@ class _HtreeView:
         return _N
 
 
+class _InitView:
+    """the ``pre_mp`` program's view: x and the initialisation edges only"""
+
+    def __init__(self, data):
+        self._d = data
+
+    @property
+    def x_dict(self):
+        return {_NODE: self._d.x}
+
+    @property
+    def edge_index_dict(self):
+        return {_INIT: self._d.init_edge_index}
+
+    @property
+    def edge_attr_dict(self):
+        return {}
+
+
 class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
     def __init__(
         self,
@@ -82,6 +104,9 @@ class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
         self._native = None  # the parent built no program yet (lazy), but make the rebuild explicit
 
     def _build_native(self) -> NativeNet:
+        if self.op_path:  # GCN / GIN: the program holds pre_mp alone (the input has no gradient, so it can be a prefix)
+            init = LayerDesc([self.pre_mp.desc(_INIT)], {_NODE: self.input_dim}, ACT_NONE, 0.0)
+            return NativeNet([_NODE], {_NODE: self.input_dim}, [_INIT], [init], readout=_NODE)
         base = super()._build_native()
         layers = list(base.layers)
         edge_types = [_EDGE, _POOL]
@@ -95,6 +120,14 @@ class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
         return _HtreeView(data, self.pre_mp is not None)
 
     def forward(self, data):
+        if self.op_path:
+            x = data.x
+            if self.pre_mp is not None:
+                x = self.native().forward(_InitView(data), self.training, self._seed, 0)[:, : self.input_dim]
+            n = data.x.size(0)
+            x = self._op_layers(x, ops.GraphPlan(data.edge_index, n), batch_norm=False)
+            x = ops.segment_mean(x, ops.GraphPlan(data.pool_edge_index, n))
+            return self._op_heads(x, data.room_mask, getattr(data, "object_mask", None))
         out = self._run(_HtreeView(data, self.pre_mp is not None))
         out = out[:, : self.native().layers[-1].out_dims[_NODE]]
         return out[data.room_mask, :]

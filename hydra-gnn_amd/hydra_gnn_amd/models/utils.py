@@ -139,12 +139,54 @@ class HeteroConv(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
 
+class GCNConv(nn.Module):
+    """Parameters of ``pyg_nn.GCNConv(in, out, add_self_loops=True)`` (reference models/utils.py:15-16): ``lin`` (glorot, no
+    bias) and a zero-initialised ``bias``.  The arithmetic is ``ops.project`` -> ``ops.gcn_propagate`` -> ``ops.bias_act_drop``."""
+
+    def __init__(self, in_channels: int, out_channels: int, add_self_loops: bool = True):
+        super().__init__()
+        if not add_self_loops:
+            raise NotImplementedError("the reference builds GCNConv(add_self_loops=True) only (models/utils.py:16)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer="glorot")
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+
+class GINConv(nn.Module):
+    """Parameters of ``pyg_nn.GINConv(nn, eps, train_eps)`` as the reference builds it (models/utils.py:17-26): ``nn`` is
+    ``Sequential(Linear, ReLU, Linear)`` and ``eps`` a [1] parameter (``train_eps=True``)."""
+
+    def __init__(self, mlp: nn.Module, eps: float = 0.0, train_eps: bool = False):
+        super().__init__()
+        if not (isinstance(mlp, nn.Sequential) and len(mlp) == 3 and isinstance(mlp[0], nn.Linear) and isinstance(mlp[1], nn.ReLU)
+                and isinstance(mlp[2], nn.Linear)):
+            raise NotImplementedError("GINConv: the native path runs the reference's Sequential(Linear, ReLU, Linear) only")
+        self.nn = mlp
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = nn.Parameter(torch.tensor([float(eps)]))
+        else:
+            self.register_buffer("eps", torch.tensor([float(eps)]))
+
+
+class BatchNorm(nn.Module):
+    """``torch_geometric.nn.BatchNorm``: a wrapper around ``torch.nn.BatchNorm1d`` (state_dict keys ``module.*``); the
+    arithmetic is ``ops.batch_norm``."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels, eps=eps, momentum=momentum, affine=True, track_running_stats=True)
+
+
 def build_conv_layer(conv_block, input_dim, output_dim, **kwargs):
-    """reference models/utils.py:9-28; only GraphSAGE is on the accelerated path (GCN/GIN: SURVEY 2 #4)."""
+    """reference models/utils.py:9-28"""
     if conv_block == "GraphSAGE":
         return SAGEConv(input_dim, output_dim, normalize=False, bias=True)
-    if conv_block in ("GCN", "GIN"):
-        raise NotImplementedError(f"conv_block {conv_block} is outside the MI355X hot path (SURVEY.md section 2, row 4)")
+    if conv_block == "GCN":
+        return GCNConv(input_dim, output_dim, add_self_loops=True)
+    if conv_block == "GIN":
+        return GINConv(nn.Sequential(nn.Linear(input_dim, output_dim), nn.ReLU(), nn.Linear(output_dim, output_dim)),
+                       eps=0.0, train_eps=True)
     return NotImplemented  # the reference returns (not raises) NotImplemented for unknown blocks
 
 

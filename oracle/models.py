@@ -25,7 +25,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .pyg_ref import (
+    BatchNorm,
     GATConv,
+    GCNConv,
+    GINConv,
     HeteroConv,
     LeafPool,
     Linear,
@@ -213,13 +216,13 @@ class HeterogeneousNeuralTreeNetwork(_HeteroBase):
 
 
 class HomogeneousNetwork(nn.Module):
-    """SAGE / GAT / GAT_edge branches of homogeneous_network.py (GCN/GIN are out of scope, SURVEY 2 #4)."""
+    """homogeneous_network.py:17-147, all five conv blocks (GCN / GIN + BatchNorm: SURVEY 8(f) row 2)."""
 
     def __init__(self, input_dim, output_dim=None, output_dim_dict=None, conv_block="GraphSAGE", hidden_dim=None,
                  num_layers=None, GAT_hidden_dims=None, GAT_heads=None, GAT_concats=None, dropout=0.25,
                  dropout_fn=default_dropout, **kwargs):
         super().__init__()
-        assert conv_block in ["GraphSAGE", "GAT", "GAT_edge"]
+        assert conv_block in ["GraphSAGE", "GAT", "GAT_edge", "GCN", "GIN"]
         self.conv_block, self.dropout, self.dropout_fn = conv_block, dropout, dropout_fn
         gat = conv_block[:3] == "GAT"
         if output_dim is not None:
@@ -249,8 +252,16 @@ class HomogeneousNetwork(nn.Module):
             self.num_layers = num_layers
             dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [mp_out]
             for l in range(num_layers):
-                self.convs.append(SAGEConv(dims[l], dims[l + 1]))
+                if conv_block == "GraphSAGE":
+                    self.convs.append(SAGEConv(dims[l], dims[l + 1]))
+                elif conv_block == "GCN":  # models/utils.py:15-16
+                    self.convs.append(GCNConv(dims[l], dims[l + 1]))
+                else:  # models/utils.py:17-26
+                    self.convs.append(GINConv(nn.Sequential(nn.Linear(dims[l], dims[l + 1]), nn.ReLU(),
+                                                            nn.Linear(dims[l + 1], dims[l + 1])), eps=0.0, train_eps=True))
             final_hidden = hidden_dim
+        if conv_block == "GIN":  # homogeneous_network.py:93-97
+            self.batch_norms = nn.ModuleList(BatchNorm(hidden_dim) for _ in range(self.num_layers))
         if self.classification_task == "all":
             n_room = output_dim_dict["rooms"] if "rooms" in output_dim_dict else output_dim_dict["room"]
             n_obj = output_dim_dict["objects"] if "objects" in output_dim_dict else output_dim_dict["object"]
@@ -269,6 +280,8 @@ class HomogeneousNetwork(nn.Module):
             else:
                 x = self.convs[l](x, edge_index)
             if l != self.num_layers - 1:
+                if self.conv_block == "GIN":  # homogeneous_network.py:133-134
+                    x = self.batch_norms[l](x)
                 x = self._act_drop(x, l)
         if self.classification_task == "room":
             return x[room_mask, :]

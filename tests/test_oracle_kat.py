@@ -160,3 +160,69 @@ def test_float32_vs_float64_and_gradcheck(block):
             sd[name].data = old
 
     assert torch.autograd.gradcheck(f, (w.detach().clone().requires_grad_(True),), eps=1e-6, atol=1e-5, rtol=1e-4)
+
+
+# ---- GCN / GIN / BatchNorm -------------------------------------------------------------------------
+def test_gcn_known_answer_and_self_loop_replacement():
+    # edges j->i: 0->1, 1->0, 2->1.  With one loop per node: deg = (2, 3, 1); lin = identity, bias 0.5, x = (1, 2, 3)
+    conv = R.GCNConv(1, 1)
+    with torch.no_grad():
+        conv.lin.weight.fill_(1.0)
+        conv.bias.fill_(0.5)
+    x = torch.tensor([[1.0], [2.0], [3.0]])
+    ei = torch.tensor([[0, 1, 2], [1, 0, 1]])
+    want = torch.tensor([[1 / 2 + 2 / math.sqrt(6)], [2 / 3 + 1 / math.sqrt(6) + 3 / math.sqrt(3)], [3.0]]) + 0.5
+    assert torch.allclose(conv(x, ei), want, atol=1e-6)
+    # an existing loop 2->2 is REPLACED by the added one (add_remaining_self_loops), not counted twice
+    ei2 = torch.tensor([[0, 1, 2, 2], [1, 0, 1, 2]])
+    assert torch.allclose(conv(x, ei2), want, atol=1e-6)
+
+
+def test_gin_known_answer():
+    mlp = torch.nn.Sequential(torch.nn.Linear(1, 1), torch.nn.ReLU(), torch.nn.Linear(1, 1))
+    conv = R.GINConv(mlp, eps=0.5, train_eps=True)
+    with torch.no_grad():
+        mlp[0].weight.fill_(2.0), mlp[0].bias.fill_(1.0), mlp[2].weight.fill_(-1.0), mlp[2].bias.fill_(0.0)
+    x = torch.tensor([[1.0], [2.0], [3.0]])
+    ei = torch.tensor([[0, 2, 1], [1, 1, 0]])
+    # s = 1.5 x_i + sum_j x_j = (3.5, 7, 4.5); 2 s + 1 = (8, 15, 10); relu; * -1
+    assert torch.allclose(conv(x, ei), torch.tensor([[-8.0], [-15.0], [-10.0]]), atol=1e-6)
+    assert list(dict(conv.named_parameters())) == ["eps", "nn.0.weight", "nn.0.bias", "nn.2.weight", "nn.2.bias"]
+
+
+def test_gcn_gin_state_dict_keys_and_batchnorm_placement():
+    kw = dict(input_dim=6, output_dim=15, hidden_dim=8, num_layers=3, dropout=0.0)
+    gcn = omodels.HomogeneousNetwork(conv_block="GCN", **kw)
+    assert sorted(gcn.state_dict()) == sorted(f"convs.{l}.{k}" for l in range(3) for k in ("bias", "lin.weight"))
+    gin = omodels.HomogeneousNetwork(conv_block="GIN", **kw)
+    keys = set(gin.state_dict())
+    assert {"convs.0.eps", "convs.0.nn.0.weight", "convs.2.nn.2.bias", "batch_norms.0.module.weight", "batch_norms.2.module.running_var",
+            "batch_norms.1.module.num_batches_tracked"} <= keys
+    # homogeneous_network.py:133-134: BatchNorm sits between the conv and the relu of every layer but the last;
+    # homogeneous_neural_tree_network.py:86-94: the H-tree loop never applies it
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(9, 6, generator=g)
+    ei = torch.randint(0, 9, (2, 20), generator=g)
+    data = type("D", (), dict(x=x, edge_index=ei, room_mask=torch.arange(9) < 3, init_edge_index=ei[:, :0], pool_edge_index=ei[:, :4]))
+    gin.train()
+    gin(data)
+    assert [int(b.module.num_batches_tracked) for b in gin.batch_norms] == [1, 1, 0]
+    tree = omodels.HomogeneousNeuralTreeNetwork(conv_block="GIN", disable_initialization=True, **kw)
+    tree.train()
+    tree(data)
+    assert [int(b.module.num_batches_tracked) for b in tree.batch_norms] == [0, 0, 0]
+
+
+@pytest.mark.parametrize("block", ["GCN", "GIN"])
+def test_gcn_gin_gradcheck(block):
+    torch.manual_seed(3)
+    net = omodels.HomogeneousNetwork(input_dim=3, output_dim=4, conv_block=block, hidden_dim=5, num_layers=2, dropout=0.0).double()
+    net.eval()  # BatchNorm on running statistics (gradcheck perturbs one input at a time)
+    x = torch.randn(7, 3, dtype=torch.float64, requires_grad=True)
+    ei = torch.randint(0, 7, (2, 15))
+    mask = torch.arange(7) < 4
+
+    def f(xx):
+        return net(type("D", (), dict(x=xx, edge_index=ei, room_mask=mask)))
+
+    assert torch.autograd.gradcheck(f, (x,), atol=1e-6)
