@@ -264,23 +264,36 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   }
 }
 
-// (Weight gradients stay on the 128x128 tile: a 256x256-tile TN launch with the bias column moved to a separate column-sum
-// kernel was measured slower, 12.1 against 10.8 ms for the config-5 backward GEMMs.)
+// Weight gradients (TN, split-K over node chunks) of a large batch also take the 256x256 tile: the 128x128 tile re-reads dZ
+// once per 128 input columns and H once per 128 packed rows (12 GB of operand traffic for the 768 x 257 x 10^6 problem of
+// config 5, 6.5 ms); the big tile halves that, provided the launch still fills the chip: 1 block per CU, so the split aims at
+// 2 x 256 blocks and needs up to ~170 slabs for 3 tiles (an earlier attempt capped at 64 slabs left a quarter of the CUs
+// idle and measured slower).
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
-  // 256x256 tiles when every problem is a plain (no split-K, no ones column) product with at least 4096 x 256 outputs
-  bool big = !want_split;
+  // 256x256 tiles when every problem is a product with at least 4096 x 192 outputs (plain) / 192 x 192 outputs over >= 2^17
+  // nodes in one problem (split-K weight gradients; narrow companions such as the 28-row last layer ride along on one tile)
+  bool big = true, tn_wide = false;
   bool any_ones = false;
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_bf16: negative size");
     any_ones = any_ones || p.aug_ones != 0;
-    if (p.aug_ones || p.M < 4096 || p.N < 192) big = false;
+    if (want_split) {
+      if (!(p.trans_a && !p.trans_b)) big = false;
+      if (p.M >= 192 && p.n_real >= 192 && p.K >= (1 << 17)) tn_wide = true;
+    } else if (p.aug_ones || p.M < 4096 || p.N < 192) big = false;
   }
+  if (want_split && !tn_wide) big = false;
   const int BT = big ? 256 : 128;
   const int BKB = big ? 32 : 64;
   int start = 0, all_tiles = 0;
-  for (int i = 0; i < gb.n; ++i) all_tiles += cdiv(gb.p[i].M, BT) * cdiv(gb.p[i].aug_ones ? (gb.p[i].n_real > 0 ? gb.p[i].n_real : 1) : gb.p[i].N, BT);
+  double work_total = 0.0;  // tiles x nodes
+  for (int i = 0; i < gb.n; ++i) {
+    const int t = cdiv(gb.p[i].M, BT) * cdiv(gb.p[i].aug_ones ? (gb.p[i].n_real > 0 ? gb.p[i].n_real : 1) : gb.p[i].N, BT);
+    all_tiles += t;
+    work_total += (double)t * gb.p[i].K;
+  }
   for (int i = 0; i < gb.n; ++i) {
     GemmProblem& p = gb.p[i];
     p.tiles_m = cdiv(p.M, BT);
@@ -288,10 +301,13 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
     const int tiles = p.tiles_m * p.tiles_n;
     int ks = 1;
     if (want_split && tiles > 0) {
-      ks = 1024 / (all_tiles > 0 ? all_tiles : 1);  // aim at ~1024 workgroups over the launch
+      // aim at 4 workgroups per CU; big tile (1 block per CU): 2 x 256 blocks shared out in proportion to the nodes each
+      // problem reduces over (the 10^4-room problems of config 5 take one block per tile, the 10^6-object ones the rest)
+      if (big) ks = (int)(512.0 * (double)p.K / (work_total > 0 ? work_total : 1.0));
+      else ks = 1024 / (all_tiles > 0 ? all_tiles : 1);
       const int max_by_k = cdiv(p.K, BKB);
       if (ks > max_by_k) ks = max_by_k;
-      if (ks > max_slabs) ks = max_slabs;
+      if (ks > (big ? max_slabs : 64)) ks = big ? max_slabs : 64;
       if (ks < 1) ks = 1;
     }
     int kchunk = cdiv(cdiv(p.K, ks), BKB) * BKB;
@@ -304,7 +320,8 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
   }
   gb.total_tiles = start;
   if (start == 0) return HMP_OK;
-  if (big) hipLaunchKernelGGL((gemm_bf16_kernel<false, 512, 256, 4, 2, 32>), dim3(start), dim3(512), 0, st, gb);
+  if (big && any_ones) hipLaunchKernelGGL((gemm_bf16_kernel<true, 512, 256, 4, 2, 32>), dim3(start), dim3(512), 0, st, gb);
+  else if (big) hipLaunchKernelGGL((gemm_bf16_kernel<false, 512, 256, 4, 2, 32>), dim3(start), dim3(512), 0, st, gb);
   else if (any_ones) hipLaunchKernelGGL((gemm_bf16_kernel<true, 256, 128, 2, 2, 64>), dim3(start), dim3(256), 0, st, gb);
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, 256, 128, 2, 2, 64>), dim3(start), dim3(256), 0, st, gb);
   HMP_LAUNCH_CHECK();

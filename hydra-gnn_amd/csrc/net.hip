@@ -55,7 +55,7 @@ struct LayerLayout {
   GatLayerS h_gat;
 };
 
-constexpr int MAX_SLABS = 64;        // split-K slabs per weight-gradient problem (large batches use them all)
+constexpr int MAX_SLABS = 192;       // split-K slabs per weight-gradient problem (large batches: 256x256 tiles x ~170 node chunks)
 constexpr int TN_DIRECT_SLABS = 16;  // small batches: more slabs only lengthen the gradient un-pack
 
 struct ProfRec {
@@ -743,7 +743,7 @@ int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std
     const size_t cnt = (ps.size() - base) < (size_t)GEMM_MAX_PROB ? (ps.size() - base) : (size_t)GEMM_MAX_PROB;
     for (size_t i = 0; i < cnt; ++i) gb.p[gb.n++] = ps[base + i];
     if (bf16) HMP_TRY(gemm_bf16_launch(gb, want_split, MAX_SLABS, st));
-    else HMP_TRY(gemm_launch(gb, want_split, MAX_SLABS, st));
+    else HMP_TRY(gemm_launch(gb, want_split, 64, st));
     if (ksplit_out)
       for (size_t i = 0; i < cnt; ++i) ksplit_out->push_back(gb.p[i].ksplit);
   }

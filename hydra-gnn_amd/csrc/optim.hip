@@ -93,6 +93,30 @@ int masked_ce_rows_launch(const float* logits, int ldl, int n_rows, int n_classe
 }
 
 // ---------------------------------------------------------------------------------------------
+// row argmax: the `.argmax(dim=1)` of the inference server (bin/room_classification_server:286); 16 lanes per row, first
+// maximum wins (torch's tie rule for distinct positions), labels as int64 so the buffer can be handed to the caller as is
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ld, int n_rows, int n_cols,
+                                                          int64_t* __restrict__ out) {
+  const int row = blockIdx.x * 16 + ((int)threadIdx.x >> 4);
+  const int lane = threadIdx.x & 15;
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  if (row < n_rows)
+    for (int c = lane; c < n_cols; c += 16) {
+      const float v = x[(int64_t)row * ld + c];
+      if (v > best || arg == 0x7fffffff) { best = v; arg = c; }
+    }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 16);
+    const int oa = __shfl_xor(arg, o, 16);
+    if (oa != 0x7fffffff && (arg == 0x7fffffff || ob > best || (ob == best && oa < arg))) { best = ob; arg = oa; }
+  }
+  if (row < n_rows && lane == 0) out[row] = arg == 0x7fffffff ? 0 : arg;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adam with coupled L2 (torch.optim.Adam semantics, base_training_job.py:181-185)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -313,6 +337,15 @@ extern "C" int hmp_masked_ce(const float* d_logits, int32_t ldl, int32_t n_rows,
   HMP_CHECK_ARG(d_logits && d_labels && d_out2, "hmp_masked_ce: null pointer");
   HMP_CHECK_ARG(n_rows >= 0 && n_classes > 0 && ldl >= n_classes && (d_grad == nullptr || ldg >= n_classes), "hmp_masked_ce: bad shape");
   return masked_ce_launch(d_logits, ldl, n_rows, n_classes, d_labels, ignored_label, d_grad, ldg, d_out2, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int hmp_argmax_rows(const float* d_x, int32_t ldx, int32_t n_rows, int32_t n_cols, int64_t* d_out, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(d_x && d_out && n_rows >= 0 && n_cols > 0 && ldx >= n_cols, "hmp_argmax_rows: bad argument");
+  if (n_rows == 0) return HMP_OK;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(cdiv(n_rows, 16)), dim3(256), 0, (hipStream_t)stream, d_x, ldx, n_rows, n_cols, d_out);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
 }
 
 extern "C" int hmp_adam_flat(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,

@@ -112,6 +112,7 @@ SIGNATURES = {
     "hmp_gat_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _I32, _VP, _VP, Plan, GatArgs, _VP, _VP, _VP, _VP, _VP,
                               _VP, _I32, _VP, _I32, _VP, _I32, _VP]),
     "hmp_masked_ce": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, _VP, _I32, _VP, _VP]),
+    "hmp_argmax_rows": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
     "hmp_adam_flat": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _VP, _VP]),
     "hmp_dropout_mask": (C.c_int, [_U64, _U32, _U32, _F32, _I32, _I32, _VP, _VP]),
     "hmp_net_create": (C.c_int, [C.POINTER(NetSpec), C.POINTER(_VP)]),

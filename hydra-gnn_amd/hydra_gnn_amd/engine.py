@@ -332,6 +332,33 @@ class NativeNet:
             self._ensure_workspace(h, flat.device)
             return _NetFunction.apply(self, h, bool(training), int(seed), int(rng_step), *self.params)
 
+    # ---- inference hot loop (bin/room_classification_server:273-299) -------------------------------------------------
+    def predict(self, data, n_classes: int) -> torch.Tensor:
+        """``forward(data).argmax(dim=1).cpu()`` of the reference's ``GnnModel.infer`` without autograd, without copying the
+        logits and with ONE small D2H: eval-mode native forward, ``hmp_argmax_rows`` on the executor's output, labels into a
+        pinned host buffer.  Returns a host int64 tensor (a view of that buffer: valid until the next call)."""
+        flat = self.flat_params(full_check=False)
+        h = self.make_batch(data)
+        dev = flat.device
+        n = int(h.c.n_out)
+        with torch.cuda.device(dev):
+            self._ensure_workspace(h, dev)
+            if getattr(self, "_pred_dev", None) is None or self._pred_dev.numel() < n or self._pred_dev.device != dev:
+                cap = max(256, 2 * n)
+                self._pred_dev = torch.empty(cap, dtype=torch.int64, device=dev)
+                self._pred_host = torch.empty(cap, dtype=torch.int64).pin_memory()
+                self._pred_done = torch.cuda.Event()
+            out_p, ld = C.c_void_p(), C.c_int32()
+            st = _lib.stream_ptr()
+            _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), flat.data_ptr(), 0, 0, 0, C.byref(out_p), C.byref(ld), st))
+            self._fwd_token += 1
+            if n > 0:
+                _lib.check(self._lib.hmp_argmax_rows(out_p.value, ld.value, n, int(n_classes), self._pred_dev.data_ptr(), st))
+                self._pred_host[:n].copy_(self._pred_dev[:n], non_blocking=True)
+            self._pred_done.record()
+            self._pred_done.synchronize()
+        return self._pred_host[:n]
+
     def _forward_raw(self, h: _BatchHolder, training: bool, seed: int, rng_step: int) -> torch.Tensor:
         out_p, ld = C.c_void_p(), C.c_int32()
         _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), self._flat.data_ptr(), int(training), seed, rng_step,

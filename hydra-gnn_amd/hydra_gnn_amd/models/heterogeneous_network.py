@@ -43,6 +43,15 @@ class _NativeModule(nn.Module):
 
         return TrainStep(self.native(), lr=lr, weight_decay=weight_decay, view=getattr(self, "_view", None), **kw)
 
+    def predict(self, data):
+        """Room labels of ``data`` on the host: ``self(data).argmax(dim=1).cpu()`` as ``GnnModel.infer`` computes it
+        (bin/room_classification_server:285-286), through the native inference path (:meth:`NativeNet.predict`)."""
+        net = self.native()
+        view = getattr(self, "_view", None)
+        labels = net.predict(view(data) if view is not None else data, net.layers[-1].out_dims[net.readout])
+        mask = getattr(data, "room_mask", None) if view is not None else None
+        return labels if mask is None else labels[mask.cpu()]
+
     def loss(self, pred, label, mask=None):
         return cross_entropy_loss(pred, label, mask)
 

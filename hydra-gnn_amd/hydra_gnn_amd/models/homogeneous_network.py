@@ -150,6 +150,14 @@ class HomogeneousNetwork(_NativeModule):
         head = lambda lin, rows: ops.bias_act_drop(ops.project(rows, lin.weight), lin.bias)
         return head(self.post_mp_room, x[room_mask, :]), head(self.post_mp_object, x[object_mask, :])
 
+    def predict(self, data):
+        if not self.op_path:
+            return super().predict(data)
+        if self.classification_task != "room":
+            raise NotImplementedError("predict() returns room labels (the server's task)")
+        with torch.no_grad():
+            return ops.argmax_rows(self(data)).cpu()
+
     def forward(self, data):
         if self.op_path:
             plan = ops.GraphPlan(data.edge_index, data.x.size(0))

@@ -257,3 +257,14 @@ def bias_act_drop(x, bias=None, relu=False, p=0.0, seed=0, rng_step=0, rng_strea
 
 def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, training) -> torch.Tensor:
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training)
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """``x.argmax(dim=1)`` (first maximum) as int64 on the device (``hmp_argmax_rows``)"""
+    _dev(x, "x")
+    x = _rows(x)
+    out = torch.empty(x.size(0), dtype=torch.int64, device=x.device)
+    if x.size(0):
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().hmp_argmax_rows(x.data_ptr(), x.stride(0), x.size(0), x.size(1), out.data_ptr(), _lib.stream_ptr()))
+    return out

@@ -143,6 +143,9 @@ int hmp_gat_bwd(const float* d_gout, int32_t ldg, const float* d_h_src, int32_t 
  * ------------------------------------------------------------------------------------------- */
 int hmp_masked_ce(const float* d_logits, int32_t ldl, int32_t n_rows, int32_t n_classes, const int64_t* d_labels,
                   int64_t ignored_label, float* d_grad, int32_t ldg, float* d_out2, void* stream);
+/* out[r] = argmax_c x[r, c] (first maximum): the `.argmax(dim=1)` of the inference loop
+ * (bin/room_classification_server:286) on the executor's output, so only the labels cross PCIe */
+int hmp_argmax_rows(const float* d_x, int32_t ldx, int32_t n_rows, int32_t n_cols, int64_t* d_out, void* stream);
 /* d_count: device float holding the valid-label count (grad_scale = 1/max(count,1)); NULL => grad_scale = 1 */
 int hmp_adam_flat(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int32_t step, const float* d_count, void* stream);

@@ -1,0 +1,83 @@
+"""Inference hot loop: ``model.predict(data)`` = the reference server's
+``self.model(data.to(device)).argmax(dim=1).cpu()`` (bin/room_classification_server:285-286) through the native eval forward,
+``hmp_argmax_rows`` and one pinned D2H of the labels.  Labels are index work: bit-exact against ``forward().argmax()``, and the
+logits they come from carry the 1e-5 oracle parity of test_gpu_models / test_gpu_gat / test_gpu_htree."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hydra_gnn_amd import ops, workloads  # noqa: E402
+from hydra_gnn_amd.data import collate_homogeneous  # noqa: E402
+from hydra_gnn_amd.models import (HeterogeneousNetwork, HeterogeneousNeuralTreeNetwork, HomogeneousNetwork)  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n,c", [(1, 1), (5, 26), (300, 15), (4097, 26), (64, 130)])
+def test_argmax_rows_first_maximum(n, c):
+    g = torch.Generator().manual_seed(n * 31 + c)
+    x = torch.randint(-3, 4, (n, c), generator=g).float()  # many ties
+    want = x.argmax(dim=1)
+    # torch documents no tie rule for argmax; pin ours (first maximum) explicitly
+    first = torch.stack([(row == row.max()).nonzero()[0, 0] for row in x])
+    got = ops.argmax_rows(x.to(DEV)).cpu()
+    assert torch.equal(got, first)
+    assert torch.equal(x.gather(1, got[:, None]), x.gather(1, want[:, None]))
+    pad = torch.full((n, c + 3), 100.0)  # a leading dimension larger than the row: the padding never wins
+    pad[:, :c] = x
+    assert torch.equal(ops.argmax_rows(pad.to(DEV)[:, :c]).cpu(), first)
+
+
+def hetero(block):
+    torch.manual_seed(1)
+    kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, dropout=0.25)
+    if block == "GraphSAGE":
+        kw.update(conv_block="GraphSAGE", hidden_dim=64, num_layers=3)
+    else:
+        kw.update(conv_block="GAT", GAT_hidden_dims=[32, 32], GAT_heads=[2, 2, 2], GAT_concats=[True, True, False])
+    return HeterogeneousNetwork(**kw).to(DEV).eval()
+
+
+@pytest.mark.parametrize("block", ["GraphSAGE", "GAT"])
+@pytest.mark.parametrize("n_graphs", [1, 7])
+def test_predict_equals_forward_argmax(block, n_graphs):
+    net = hetero(block)
+    for seed in (3, 4, 5):  # consecutive frames of different sizes through one workspace
+        batch = workloads.mp3d_like_batch(n_graphs, seed).to(DEV)
+        with torch.no_grad():
+            want = net(batch).argmax(dim=1).cpu()
+        got = net.predict(batch)
+        assert got.dtype == torch.int64 and not got.is_cuda
+        assert torch.equal(got, want)
+
+
+def test_predict_htree_and_homogeneous():
+    torch.manual_seed(2)
+    dims = {"object": 306, "room": 6, "object-room": 6, "room-room": 6, "object_virtual": 306, "room_virtual": 6}
+    tree = HeterogeneousNeuralTreeNetwork(input_dim_dict=dims, output_dim=26,
+                                          conv_block="GraphSAGE", hidden_dim=32, num_layers=3, disable_initialization=True).to(DEV).eval()
+    batch = workloads.htree_batch(5, seed=9).to(DEV)
+    with torch.no_grad():
+        want = tree(batch).argmax(dim=1).cpu()
+    assert torch.equal(tree.predict(batch), want) and want.numel() == int(batch["room_virtual"].num_nodes)
+    rng = np.random.Generator(np.random.PCG64(7))
+    graphs = collate_homogeneous([workloads.stanford_like_graph(rng) for _ in range(6)]).to(DEV)
+    for block in ("GraphSAGE", "GCN", "GIN"):
+        net = HomogeneousNetwork(input_dim=6, output_dim=15, conv_block=block, hidden_dim=32, num_layers=3).to(DEV).eval()
+        with torch.no_grad():
+            want = net(graphs).argmax(dim=1).cpu()
+        assert torch.equal(net.predict(graphs), want) and want.numel() == 6
+
+
+def test_predict_leaves_training_state_alone():
+    """a predict() between forward and backward would overwrite the activations: the engine must notice"""
+    from hydra_gnn_amd import _lib
+
+    net = hetero("GraphSAGE").train()
+    batch = workloads.mp3d_like_batch(3, 3).to(DEV)
+    pred = net(batch)
+    net.predict(batch)
+    with pytest.raises(_lib.HydraMPError):
+        pred.sum().backward()
