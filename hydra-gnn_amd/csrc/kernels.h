@@ -168,6 +168,7 @@ struct AggArgs {
   int n;
   int total_blocks;
   int mean;  // divide every gather by max(deg,1)
+  int xcd;   // large launches: consecutive row ranges stay on one XCD (block counts padded to 8 per entry), see agg_fwd_launch
   NetState* state;  // status bits (fused cross entropy: label out of range)
   AggDst d[HMP_MAX_NODE_TYPES];
 };
@@ -203,6 +204,7 @@ struct TAggArgs {
   int n;
   int total_blocks;
   int mean;
+  int xcd;  // as AggArgs::xcd
   // one extra block sums the per-row {loss, valid} pairs of the loss in fixed order -> fin_out2 / fin_state (null: off)
   const float* fin_row_lv;
   int fin_rows;

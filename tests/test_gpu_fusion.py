@@ -261,3 +261,41 @@ def test_bf16_compute_mode_on_a_large_graph():
     a = net2(small.to(DEV)).detach().clone()
     net2.native().set_compute("bf16")
     assert torch.equal(net2(small.to(DEV)), a)
+
+
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_large_launch_xcd_row_mapping_is_bit_identical(hidden, monkeypatch):
+    """>= 65536 rows: the aggregation kernels hand every XCD one contiguous eighth of the rows (L2 locality).  Which block
+    computes a row must not change the row: logits and every gradient are bit-identical to the plain block order, and the
+    logits stay within tolerance of the float64 oracle (sums over 10^5 rows are compared at 1e-4)."""
+    kw = dict(input_dim_dict={"objects": 64, "rooms": 64}, output_dim=26, conv_block="GraphSAGE", hidden_dim=hidden, num_layers=3, dropout=0.0)
+    g = workloads.big_hetero_graph(n_obj=70001, n_rooms=701, deg=6, feat_dim=64, seed=5)
+    ora, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+    net.eval()
+    gd = g.to(DEV)
+    y = gd["rooms"].y
+
+    def fwd_bwd():
+        for p in net.parameters():
+            p.grad = None
+        pred = net(gd)
+        net.loss(pred, y, y != 25).backward()
+        return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    out, grads = fwd_bwd()
+    for env in ({"HMP_AGG_XCD": "0"},):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out0, grads0 = fwd_bwd()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert torch.equal(out, out0), env
+        for k in grads:
+            assert torch.equal(grads[k], grads0[k]), (k, env)
+    o64 = copy.deepcopy(ora).double().eval()
+    b64 = g.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    with torch.no_grad():
+        ref = o64(b64)
+    torch.testing.assert_close(out.cpu().double(), ref, atol=1e-4, rtol=1e-4)
