@@ -136,6 +136,8 @@ SIGNATURES = {
     "hmp_timer_destroy": (None, [_VP]),
     "hmp_net_profile": (C.c_int, [_VP, _I32]),
     "hmp_net_profile_read": (C.c_int, [_VP, C.POINTER(_F32), C.POINTER(_I32)]),
+    "hmp_object_edges_count": (C.c_int, [_VP, _VP, _VP, _I32, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP]),
+    "hmp_object_edges_fill": (C.c_int, [_VP, _VP, _VP, _I32, C.c_double, C.c_double, C.c_double, _VP, _VP, _I32, _VP]),
     "hmp_gcn_norm": (C.c_int, [Plan, _VP, _VP]),
     "hmp_segment_wsum": (C.c_int, [_VP, _I32, _I32, Plan, _I32, _VP, _VP, _VP, _I32, _VP]),
     "hmp_bias_act_drop_fwd": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I32, _F32, _U64, _U32, _U32, _VP, _I32, _VP]),

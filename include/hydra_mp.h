@@ -332,6 +332,18 @@ int hmp_batchnorm_bwd(const float* d_g, int32_t ldg, const float* d_x, int32_t l
                       const float* d_gamma, const float* d_save, int32_t training, float* d_gx, int32_t ldgx, float* d_ggamma,
                       float* d_gbeta, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 10. Object connectivity of a room-object scene graph (csrc/dsg.hip).  Replaces the per-frame Python loop
+ *     add_object_connectivity (src/hydra_gnn/preprocess_dsgs.py:191-225) with its predicates _is_on / _is_under / _is_near
+ *     (:89-180), float64 like numpy.  Objects in the reference's visiting order (ascending node id); d_room[i] = room index or
+ *     < 0.  count: d_count[i] = #{j < i in i's room : on | under | near}, d_offset = its exclusive scan (d_offset[n] = total).
+ *     fill: d_edges [2][total] = (i, j) pairs ordered by i then j -- the reference's insertion order.
+ * ------------------------------------------------------------------------------------------- */
+int hmp_object_edges_count(const double* d_pos, const double* d_size, const int32_t* d_room, int32_t n, double threshold_near,
+                           double max_near, double max_on, int32_t* d_count, int32_t* d_offset, void* stream);
+int hmp_object_edges_fill(const double* d_pos, const double* d_size, const int32_t* d_room, int32_t n, double threshold_near,
+                          double max_near, double max_on, const int32_t* d_offset, int32_t* d_edges, int32_t total, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

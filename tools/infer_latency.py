@@ -54,6 +54,32 @@ def main():
         for f in frames[:4]:
             assert torch.equal(ref_expr(f), net.predict(f))
         out[name] = {"forward_argmax_cpu": a, "predict": b}
+    # ---- the step before the model: spark_dsg JSON frame -> HeteroData (hydra_gnn_amd/dsg.py), on the reference's test graph
+    import os
+
+    from hydra_gnn_amd import dsg
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dsg_x8F5xyUWy9e.json")
+    raw = json.load(open(path))
+    net6 = HeterogeneousNetwork(input_dim_dict={"objects": 6, "rooms": 6}, output_dim=26, dropout=0.25, **nets["sage_h64_l3"]).to(DEV).eval()
+    stages = {}
+
+    def stage(name, fn, reps=50):
+        r = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter_ns()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        stages[name] = round((time.perf_counter_ns() - t0) * 1e-3 / reps, 1)
+        return r
+
+    sg = stage("parse_static_layers_us", lambda: dsg.load_dsg_json(raw))
+    rog = stage("room_object_graph_us", lambda: dsg.RoomObjectGraph(sg))
+    oo = stage("object_connectivity_hip_us", lambda: dsg.object_connectivity(rog, 1.5, 2.0, 0.2, DEV))
+    data = stage("to_hetero_data_us", lambda: dsg.to_hetero_data(rog, oo, None, DEV))
+    stage("predict_us", lambda: net6.predict(data))
+    out["dsg_frame_62_objects"] = stages
     print(json.dumps(out))
 
 
