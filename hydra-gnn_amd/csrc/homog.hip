@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void gcn_norm_kernel(const int* __restrict__ r
   dinv[row] = 1.f / sqrtf((float)deg);
 }
 
-// y = dropout(act(x + bias)); the keep-mask is the engine's (hmp_dropout_mask replays it: element (row, col) of an [n, F] tensor)
+// y = dropout(act(x + bias)), act = HMP_ACT_NONE / RELU / ELU; the keep-mask is the engine's (hmp_dropout_mask replays it: element
+// (row, col) of an [n, F] tensor).  A dropped element is stored as -0.0f, a kept zero as +0.0f (the engine's convention), so the
+// backward reads everything it needs off y.
 __global__ __launch_bounds__(256) void bias_act_drop_kernel(const float* __restrict__ x, int ldx, int n, int F,
-                                                            const float* __restrict__ bias, int relu, int drop_on, DropCfg cfg,
+                                                            const float* __restrict__ bias, int act, int drop_on, DropCfg cfg,
                                                             float* __restrict__ y, int ldy) {
   const int qpr = (F + 3) >> 2;
   const int64_t total = (int64_t)n * qpr;
@@ -79,21 +81,31 @@ __global__ __launch_bounds__(256) void bias_act_drop_kernel(const float* __restr
     for (int i = 0; i < 4; ++i) {
       if (c + i >= F) continue;
       float v = x[(int64_t)row * ldx + c + i] + (bias ? bias[c + i] : 0.f);
-      if (relu) v = fmaxf(v, 0.f);
-      if (drop_on) v = keep[i] ? v * cfg.scale : 0.f;
+      if (act == HMP_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (act == HMP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+      if (drop_on) v = keep[i] ? (v * cfg.scale + 0.0f) : -0.0f;
+      else if (act != HMP_ACT_NONE) v = v + 0.0f;  // a kept -0.0 becomes +0.0: the sign of zero is reserved for "dropped"
       y[(int64_t)row * ldy + c + i] = v;
     }
   }
 }
 
-// gx = g * d y / d x given the forward OUTPUT y: with relu (dropout only ever follows a relu) y > 0 <=> kept and active
+// gx = g * d y / d x from the forward OUTPUT y (scale = 1/(1-p), 1 without dropout):
+//   dropped (y is -0.0f) -> 0;  relu: y > 0 ? g*scale : 0;  elu: y > 0 ? g*scale : g*(y + scale)   [y = scale*elu(x), elu' = elu + 1]
 __global__ __launch_bounds__(256) void bias_act_drop_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy,
-                                                                int n, int F, int relu, float scale, float* __restrict__ gx, int ldgx) {
+                                                                int n, int F, int act, float scale, float* __restrict__ gx, int ldgx) {
   const int64_t total = (int64_t)n * F;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(e / F), c = (int)(e % F);
     const float gv = g[(int64_t)row * ldg + c];
-    gx[(int64_t)row * ldgx + c] = relu ? (y[(int64_t)row * ldy + c] > 0.f ? gv * scale : 0.f) : gv;
+    float r = gv;
+    if (act != HMP_ACT_NONE) {
+      const float yv = y[(int64_t)row * ldy + c];
+      if (__float_as_uint(yv) == 0x80000000u) r = 0.f;
+      else if (yv > 0.f) r = gv * scale;
+      else r = act == HMP_ACT_ELU ? gv * (yv + scale) : 0.f;
+    }
+    gx[(int64_t)row * ldgx + c] = r;
   }
 }
 
@@ -254,11 +266,12 @@ extern "C" int hmp_segment_wsum(const float* d_x, int32_t ldx, int32_t F, hmp_pl
   return HMP_OK;
 }
 
-extern "C" int hmp_bias_act_drop_fwd(const float* d_x, int32_t ldx, int32_t n_rows, int32_t F, const float* d_bias, int32_t relu,
+extern "C" int hmp_bias_act_drop_fwd(const float* d_x, int32_t ldx, int32_t n_rows, int32_t F, const float* d_bias, int32_t act,
                                      float p, uint64_t seed, uint32_t rng_step, uint32_t rng_stream, float* d_y, int32_t ldy,
                                      void* stream) {
   HMP_CHECK_ARG(d_x && d_y && n_rows >= 0 && F > 0 && ldx >= F && ldy >= F && p >= 0.f && p < 1.f, "hmp_bias_act_drop_fwd: bad argument");
-  HMP_CHECK_ARG(p == 0.f || relu, "hmp_bias_act_drop_fwd: dropout is only defined after the relu (the backward reads the mask off y > 0)");
+  HMP_CHECK_ARG(act == HMP_ACT_NONE || act == HMP_ACT_RELU || act == HMP_ACT_ELU, "hmp_bias_act_drop_fwd: unknown activation %d", act);
+  HMP_CHECK_ARG(p == 0.f || act != HMP_ACT_NONE, "hmp_bias_act_drop_fwd: dropout is only defined after an activation (the reference never drops a raw sum)");
   if (n_rows == 0) return HMP_OK;
   DropCfg cfg;
   cfg.k0 = (uint32_t)seed; cfg.k1 = (uint32_t)(seed >> 32);
@@ -266,18 +279,18 @@ extern "C" int hmp_bias_act_drop_fwd(const float* d_x, int32_t ldx, int32_t n_ro
   cfg.thresh = drop_thresh(p); cfg.scale = 1.f / (1.f - p);
   cfg.step_dev = nullptr;
   hipLaunchKernelGGL(bias_act_drop_kernel, dim3(grid_for((int64_t)n_rows * ((F + 3) >> 2))), dim3(256), 0, (hipStream_t)stream, d_x, ldx,
-                     n_rows, F, d_bias, relu, p > 0.f ? 1 : 0, cfg, d_y, ldy);
+                     n_rows, F, d_bias, act, p > 0.f ? 1 : 0, cfg, d_y, ldy);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
 
 extern "C" int hmp_bias_act_drop_bwd(const float* d_g, int32_t ldg, const float* d_y, int32_t ldy, int32_t n_rows, int32_t F,
-                                     int32_t relu, float p, float* d_gx, int32_t ldgx, void* stream) {
-  HMP_CHECK_ARG(d_g && d_gx && (d_y || !relu) && n_rows >= 0 && F > 0 && ldg >= F && ldgx >= F && p >= 0.f && p < 1.f,
+                                     int32_t act, float p, float* d_gx, int32_t ldgx, void* stream) {
+  HMP_CHECK_ARG(d_g && d_gx && (d_y || act == HMP_ACT_NONE) && n_rows >= 0 && F > 0 && ldg >= F && ldgx >= F && p >= 0.f && p < 1.f,
                 "hmp_bias_act_drop_bwd: bad argument");
   if (n_rows == 0) return HMP_OK;
   hipLaunchKernelGGL(bias_act_drop_bwd_kernel, dim3(grid_for((int64_t)n_rows * F)), dim3(256), 0, (hipStream_t)stream, d_g, ldg, d_y,
-                     ldy, n_rows, F, relu, 1.f / (1.f - p), d_gx, ldgx);
+                     ldy, n_rows, F, act, 1.f / (1.f - p), d_gx, ldgx);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

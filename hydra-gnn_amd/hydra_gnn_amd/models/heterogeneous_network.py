@@ -41,6 +41,9 @@ class _NativeModule(nn.Module):
         """Fused native training step (fwd + masked CE + bwd [+ all-reduce] + Adam), see engine.TrainStep."""
         from ..engine import TrainStep
 
+        if getattr(self, "classification_task", "room") != "room":
+            raise NotImplementedError("the fused training step computes ONE masked cross entropy (room labels); the two-headed "
+                                      "task trains through loss.backward() like the reference's SemiSupervisedTrainingJob")
         return TrainStep(self.native(), lr=lr, weight_decay=weight_decay, view=getattr(self, "_view", None), **kw)
 
     def predict(self, data):

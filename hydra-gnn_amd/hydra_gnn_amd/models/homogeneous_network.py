@@ -61,10 +61,7 @@ class HomogeneousNetwork(_NativeModule):
             raise NotImplementedError(f"conv_block {conv_block}")
         self.conv_block = conv_block
         self.op_path = conv_block in ("GCN", "GIN")
-        if output_dim is None:
-            if not self.op_path:
-                raise NotImplementedError("classification_task='all' with GraphSAGE / GAT: the native program reads out ONE "
-                                          "node set (SURVEY.md section 2, row 8); GCN / GIN support it")
+        if output_dim is None:  # two-headed task of the semi-supervised Stanford job (reference :57-63,99-120)
             assert output_dim_dict is not None
             self.classification_task = "all"
             output_dim = hidden_dim
@@ -75,10 +72,12 @@ class HomogeneousNetwork(_NativeModule):
         self.num_layers = num_layers if not gat else len(GAT_heads)
         self.dropout = dropout
         self.input_dim = input_dim
+        all_task = self.classification_task == "all"
+        gat_dims = (list(GAT_hidden_dims) if all_task else list(GAT_hidden_dims) + [output_dim]) if gat else None
         if conv_block == "GAT":
-            self.convs = build_GAT_conv_layers(input_dim, GAT_hidden_dims + [output_dim], GAT_heads, GAT_concats, dropout=dropout)
+            self.convs = build_GAT_conv_layers(input_dim, gat_dims, GAT_heads, GAT_concats, dropout=dropout)
         elif conv_block == "GAT_edge":
-            self.convs = build_GAT_conv_layers(input_dim, GAT_hidden_dims + [output_dim], GAT_heads, GAT_concats,
+            self.convs = build_GAT_conv_layers(input_dim, gat_dims, GAT_heads, GAT_concats,
                                                dropout=dropout, edge_dim=3, add_self_loop=True,
                                                fill_value=torch.zeros(3, dtype=torch.float64))
         else:
@@ -89,8 +88,9 @@ class HomogeneousNetwork(_NativeModule):
         if self.classification_task == "all":  # reference :99-120
             n_room = output_dim_dict["rooms"] if "rooms" in output_dim_dict else output_dim_dict["room"]
             n_obj = output_dim_dict["objects"] if "objects" in output_dim_dict else output_dim_dict["object"]
-            self.post_mp_room = nn.Linear(hidden_dim, n_room)
-            self.post_mp_object = nn.Linear(hidden_dim, n_obj)
+            final_hidden = (gat_dims[-1] * GAT_heads[-1] if GAT_concats[-1] else gat_dims[-1]) if gat else hidden_dim
+            self.post_mp_room = nn.Linear(final_hidden, n_room)
+            self.post_mp_object = nn.Linear(final_hidden, n_obj)
         self._init_native()
 
     def _build_native(self) -> NativeNet:
@@ -111,10 +111,17 @@ class HomogeneousNetwork(_NativeModule):
         return _HomoView(data)
 
     # ---- GCN / GIN: op-by-op native path ---------------------------------------------------------------------------------
+    def _drop_stream(self, l: int) -> int:
+        """RNG tensor id of the feature dropout after conv ``l`` (the native program numbers its layers from 0, node type 0)"""
+        return 8 * l
+
     def _act_drop(self, x, l, bias=None):
-        """relu + dropout after layer ``l`` (reference :135-136); the keep-mask is tensor ``8 * l`` of this call's RNG step"""
+        """activation (relu; elu for GAT) + dropout after layer ``l`` (reference :135-136,141-142); the keep-mask is tensor
+        ``_drop_stream(l)`` of this call's RNG step"""
         p = self.dropout if self.training else 0.0
-        return ops.bias_act_drop(x, bias, relu=True, p=p, seed=self._seed, rng_step=self._rng_step, rng_stream=8 * l)
+        gat = self.conv_block[:3] == "GAT"
+        return ops.bias_act_drop(x, bias, relu=not gat, elu=gat, p=p, seed=self._seed, rng_step=self._rng_step,
+                                 rng_stream=self._drop_stream(l))
 
     def _op_layers(self, x, plan, batch_norm=True):
         """reference :125-136 for conv_block GCN / GIN; ``batch_norm`` False = the H-tree variant's loop, which never
@@ -151,10 +158,10 @@ class HomogeneousNetwork(_NativeModule):
         return head(self.post_mp_room, x[room_mask, :]), head(self.post_mp_object, x[object_mask, :])
 
     def predict(self, data):
-        if not self.op_path:
-            return super().predict(data)
         if self.classification_task != "room":
             raise NotImplementedError("predict() returns room labels (the server's task)")
+        if not self.op_path:
+            return super().predict(data)
         with torch.no_grad():
             return ops.argmax_rows(self(data)).cpu()
 
@@ -165,4 +172,4 @@ class HomogeneousNetwork(_NativeModule):
             return self._op_heads(x, data.room_mask, ~data.room_mask)
         out = self._run(_HomoView(data))
         out = out[:, : self.native().layers[-1].out_dims[_NODE]]
-        return out[data.room_mask, :]
+        return self._op_heads(out, data.room_mask, ~data.room_mask)

@@ -116,6 +116,10 @@ class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
             edge_types.append(_INIT)
         return NativeNet([_NODE], {_NODE: self.input_dim}, edge_types, layers, readout=_NODE, pool_edge_type=_POOL)
 
+    def _drop_stream(self, l: int) -> int:
+        # with pre_mp inside the native program (SAGE / GAT) the convs are its layers 1..L
+        return 8 * (l + (1 if (self.pre_mp is not None and not self.op_path) else 0))
+
     def _view(self, data):
         return _HtreeView(data, self.pre_mp is not None)
 
@@ -130,4 +134,4 @@ class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
             return self._op_heads(x, data.room_mask, getattr(data, "object_mask", None))
         out = self._run(_HtreeView(data, self.pre_mp is not None))
         out = out[:, : self.native().layers[-1].out_dims[_NODE]]
-        return out[data.room_mask, :]
+        return self._op_heads(out, data.room_mask, getattr(data, "object_mask", None))  # reference :96-109

@@ -146,16 +146,16 @@ class _WSum(torch.autograd.Function):
 
 class _BiasActDrop(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, relu: bool, p: float, seed: int, rng_step: int, rng_stream: int):
+    def forward(ctx, x, bias, act: int, p: float, seed: int, rng_step: int, rng_stream: int):
         _dev(x, "x")
         x = _rows(x)
         y = torch.empty((x.size(0), x.size(1)), dtype=torch.float32, device=x.device)
         if x.numel():
             with torch.cuda.device(x.device):
                 _lib.check(_lib.load().hmp_bias_act_drop_fwd(x.data_ptr(), x.stride(0), x.size(0), x.size(1),
-                                                             bias.data_ptr() if bias is not None else None, int(relu), float(p), seed,
+                                                             bias.data_ptr() if bias is not None else None, int(act), float(p), seed,
                                                              rng_step, rng_stream, y.data_ptr(), y.stride(0), _lib.stream_ptr()))
-        ctx.relu, ctx.p, ctx.has_bias = relu, float(p), bias is not None
+        ctx.act, ctx.p, ctx.has_bias = int(act), float(p), bias is not None
         ctx.save_for_backward(y)
         return y
 
@@ -163,12 +163,12 @@ class _BiasActDrop(torch.autograd.Function):
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
         g = _rows(g)
-        if ctx.relu:
+        if ctx.act != _lib.ACT_NONE:
             gx = torch.empty_like(y)
             if y.numel():
                 with torch.cuda.device(y.device):
                     _lib.check(_lib.load().hmp_bias_act_drop_bwd(g.data_ptr(), g.stride(0), y.data_ptr(), y.stride(0), y.size(0), y.size(1),
-                                                                 1, ctx.p, gx.data_ptr(), gx.stride(0), _lib.stream_ptr()))
+                                                                 ctx.act, ctx.p, gx.data_ptr(), gx.stride(0), _lib.stream_ptr()))
         else:
             gx = g
         gb = _colsum(gx) if ctx.has_bias and ctx.needs_input_grad[1] else None
@@ -251,8 +251,9 @@ def gin_propagate(z: torch.Tensor, plan: GraphPlan, eps: torch.Tensor) -> torch.
     return _WSum.apply(z, plan, False, eps)
 
 
-def bias_act_drop(x, bias=None, relu=False, p=0.0, seed=0, rng_step=0, rng_stream=0) -> torch.Tensor:
-    return _BiasActDrop.apply(x, bias, relu, p, seed, rng_step, rng_stream)
+def bias_act_drop(x, bias=None, relu=False, p=0.0, seed=0, rng_step=0, rng_stream=0, elu=False) -> torch.Tensor:
+    act = _lib.ACT_ELU if elu else (_lib.ACT_RELU if relu else _lib.ACT_NONE)
+    return _BiasActDrop.apply(x, bias, act, p, seed, rng_step, rng_stream)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, training) -> torch.Tensor:

@@ -308,8 +308,9 @@ int hmp_collate_edges(const int64_t* d_src, int64_t e_total, const int64_t* d_ed
  *    segment_wsum: d_w != NULL (GCN): out_i = w_i ( sum_{j->i, j != i} w_j x_j + w_i x_i )
  *                  d_w == NULL (GIN): out_i = sum_{j->i} x_j + (1 + *d_eps) x_i      (d_eps NULL = 0)
  *                  transpose != 0 runs the same sum over the CSC lists (= the gradient w.r.t. x).
- *    bias_act_drop: y = dropout_p(relu?(x + bias)); keep-mask = hmp_dropout_mask(seed, rng_step, rng_stream, p, n, F);
- *                  bwd reads the mask off the forward output (y > 0), so p > 0 requires relu.
+ *    bias_act_drop: y = dropout_p(act(x + bias)), act = HMP_ACT_NONE / RELU / ELU; keep-mask = hmp_dropout_mask(seed, rng_step,
+ *                  rng_stream, p, n, F); a dropped element is stored as -0.0f, so the backward needs y only; p > 0 requires an
+ *                  activation.
  *    colsum / rowdot_sum: out[c] = sum_r g[r,c];  *out = sum_{r,c} a[r,c] b[r,c]   (fixed summation order)
  *    batchnorm:    torch.nn.BatchNorm1d semantics (training: batch statistics, running stats updated in place with the
  *                  unbiased variance; eval: running statistics).  d_save [2][F] = {mean, 1/sqrt(var+eps)} for the backward.
@@ -317,11 +318,11 @@ int hmp_collate_edges(const int64_t* d_src, int64_t e_total, const int64_t* d_ed
 int hmp_gcn_norm(hmp_plan plan, float* d_dinv, void* stream);
 int hmp_segment_wsum(const float* d_x, int32_t ldx, int32_t F, hmp_plan plan, int32_t transpose, const float* d_w,
                      const float* d_eps, float* d_out, int32_t ldo, void* stream);
-int hmp_bias_act_drop_fwd(const float* d_x, int32_t ldx, int32_t n_rows, int32_t F, const float* d_bias, int32_t relu,
+int hmp_bias_act_drop_fwd(const float* d_x, int32_t ldx, int32_t n_rows, int32_t F, const float* d_bias, int32_t act,
                           float p, uint64_t seed, uint32_t rng_step, uint32_t rng_stream, float* d_y, int32_t ldy,
                           void* stream);
 int hmp_bias_act_drop_bwd(const float* d_g, int32_t ldg, const float* d_y, int32_t ldy, int32_t n_rows, int32_t F,
-                          int32_t relu, float p, float* d_gx, int32_t ldgx, void* stream);
+                          int32_t act, float p, float* d_gx, int32_t ldgx, void* stream);
 int hmp_colsum(const float* d_g, int32_t ldg, int32_t n_rows, int32_t F, float* d_out, void* stream);
 int hmp_rowdot_sum(const float* d_a, int32_t lda, const float* d_b, int32_t ldb, int32_t n_rows, int32_t F, float* d_out,
                    void* stream);

@@ -301,7 +301,6 @@ class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
                  dropout_fn=default_dropout, **kwargs):
         super().__init__(input_dim, output_dim, output_dim_dict, conv_block, hidden_dim, num_layers, GAT_hidden_dims, GAT_heads,
                          GAT_concats, dropout, dropout_fn=dropout_fn, **kwargs)
-        assert self.classification_task == "room"
         self.pre_mp = None if disable_initialization else GATConv(input_dim, input_dim, heads=1, concat=False, dropout=0.0,
                                                                   add_self_loops=False)
         self.post_mp_pool = LeafPool()
@@ -318,4 +317,7 @@ class HomogeneousNeuralTreeNetwork(HomogeneousNetwork):
             if l != self.num_layers - 1:
                 x = self._act_drop(x, l)
         x = self.post_mp_pool(x, data.pool_edge_index)
-        return x[data.room_mask, :]
+        if self.classification_task == "room":
+            return x[data.room_mask, :]
+        x = self._act_drop(x, self.num_layers - 1)  # homogeneous_neural_tree_network.py:100-109
+        return self.post_mp_room(x[data.room_mask, :]), self.post_mp_object(x[data.object_mask, :])
