@@ -269,6 +269,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
 // config 5, 6.5 ms); the big tile halves that, provided the launch still fills the chip: 1 block per CU, so the split aims at
 // 2 x 256 blocks and needs up to ~170 slabs for 3 tiles (an earlier attempt capped at 64 slabs left a quarter of the CUs
 // idle and measured slower).
+// Measured on top of this kernel and rejected (config 5, 28.7 ms/step): a bf16 image of the stacked weights as B operand (half
+// the bytes, the same number of requests per stage: forward 5.14 -> 5.19 ms, backward 8.25 -> 8.99 ms) and two stages of register
+// prefetch instead of one (256 VGPRs + scratch spills: forward 5.50 ms, backward 13.5 ms).  Neither bytes nor requests in flight
+// per CU is what holds the 256x256 tile at ~47 us; the next candidate is a B-stationary persistent form (the 256 x 256 bf16
+// weight tile fits LDS) with LDS-DMA staging of A.
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
   // 256x256 tiles when every problem is a product with at least 4096 x 192 outputs (plain) / 192 x 192 outputs over >= 2^17
