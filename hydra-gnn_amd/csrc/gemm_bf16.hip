@@ -39,9 +39,36 @@ struct StageRegs {
 // measured): a 128x128 tile re-reads A once per 128 output columns and B once per 128 output rows (12 GB for the config-5
 // layer-0 projection), a 256x256 tile halves both.
 //  kcontig: slot q covers row q / 16, k4 = (q % 16) * 4      rcontig: slot q covers k = q / (ROWS/4), r4 = (q % (ROWS/4)) * 4
+// bf_load_fast only ISSUES the stage's loads (clamped addresses, nothing reads the registers); bf_mask zeroes what lies outside
+// the operand when the stage is consumed, one iteration later.  With the masks applied in the loader the compiler had to wait
+// for every load right there -- before the MFMAs the prefetch was meant to overlap with (and, with the layout branch inside the
+// loop, even between one load and the next).
 template <int NT, int ROWS, int BKB>
 __device__ __forceinline__ void bf_load_fast(StageRegs<ROWS * BKB / 4 / NT>& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R,
                                              int k0, int kend) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
+  const int tid = threadIdx.x;
+  if (kcontig) {
+#pragma unroll
+    for (int i = 0; i < BNV; ++i) {
+      const int q = tid + i * NT;
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
+      const int gr = r0 + r, gk = k0 + k4;
+      t.v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(gr < R ? gr : R - 1) * ld + (gk < kend ? gk : k0));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < BNV; ++i) {
+      const int q = tid + i * NT;
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      const int gk = k0 + k;
+      t.v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(gk < kend ? gk : k0) * ld + (r0 + r4));
+    }
+  }
+}
+
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_mask(StageRegs<ROWS * BKB / 4 / NT>& t, int kcontig, int r0, int R, int k0, int kend) {
   constexpr int BNV = ROWS * BKB / 4 / NT;
   const int tid = threadIdx.x;
 #pragma unroll
@@ -49,18 +76,13 @@ __device__ __forceinline__ void bf_load_fast(StageRegs<ROWS * BKB / 4 / NT>& t, 
     const int q = tid + i * NT;
     if (kcontig) {
       const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
-      const int gr = r0 + r, gk = k0 + k4;
-      const bool rl = gr < R;
-      const int gkc = gk < kend ? gk : k0;
-      const float4 val = *reinterpret_cast<const float4*>(p + (int64_t)(rl ? gr : R - 1) * ld + gkc);
-      t.v[i] = make_float4(rl && gk + 0 < kend ? val.x : 0.f, rl && gk + 1 < kend ? val.y : 0.f, rl && gk + 2 < kend ? val.z : 0.f,
-                           rl && gk + 3 < kend ? val.w : 0.f);
+      const int gk = k0 + k4;
+      const bool rl = r0 + r < R;
+      t.v[i] = make_float4(rl && gk + 0 < kend ? t.v[i].x : 0.f, rl && gk + 1 < kend ? t.v[i].y : 0.f, rl && gk + 2 < kend ? t.v[i].z : 0.f,
+                           rl && gk + 3 < kend ? t.v[i].w : 0.f);
     } else {
-      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
-      const int gk = k0 + k;
-      const bool kl = gk < kend;
-      const float4 val = *reinterpret_cast<const float4*>(p + (int64_t)(kl ? gk : k0) * ld + (r0 + r4));
-      t.v[i] = kl ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = q / (ROWS / 4);
+      if (k0 + k >= kend) t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -149,7 +171,10 @@ __device__ __forceinline__ float bf_act_mask(float h, int act, bool keep, float 
 }
 
 // NT threads, ROWS x ROWS tile, waves WMW (along M) x WNW (along N), every wave (ROWS/WMW) x (ROWS/WNW) = MI x NI MFMA tiles
-template <bool ONES, int NT, int ROWS, int WMW, int WNW, int BKB>
+// FORM fixes the operand layouts at compile time (0: NT = x * W^T, 1: NN = dZ * W, 2: TN = dZ^T * [x | 1]; 3: per problem at run
+// time).  With run-time layouts the branches sit inside the unrolled load / LDS-read loops and every access waits for the one
+// before it.
+template <bool ONES, int NT, int ROWS, int WMW, int WNW, int BKB, int FORM>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const GemmBatch gb) {
   constexpr int MI = ROWS / WMW / 32, NI = ROWS / WNW / 32;
   constexpr int BPITCH = BKB + 8;
@@ -167,8 +192,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   const int m0 = (grp * 8 + within % rows_in_grp) * ROWS, n0 = (within / rows_in_grp) * ROWS;
   const int kbeg = z * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
-  const int a_kc = P.trans_a ? 0 : 1;
-  const int b_kc = P.trans_b ? 1 : 0;
+  const int a_kc = FORM == 3 ? (P.trans_a ? 0 : 1) : (FORM == 2 ? 0 : 1);
+  const int b_kc = FORM == 3 ? (P.trans_b ? 1 : 0) : (FORM == 0 ? 1 : 0);
   // block-uniform loader choice
   const bool a_al = (P.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(P.A) & 15) == 0;
   const bool b_al = (P.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(P.B) & 15) == 0;
@@ -207,6 +232,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   };
   load(kbeg);
   for (int kt = kbeg; kt < kend; kt += BKB) {
+    if (a_fast) bf_mask<NT, ROWS, BKB>(ra, a_kc, m0, P.M, kt, kend);
+    if (b_fast) bf_mask<NT, ROWS, BKB>(rb, b_kc, n0, P.n_real, kt, kend);
     bf_store<NT, ROWS, BKB>(ra, As, a_kc);
     bf_store<NT, ROWS, BKB>(rb, Bs, b_kc);
     __syncthreads();
@@ -233,24 +260,40 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   }
 
   // D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // Epilogue without branches between memory operations: the problem's fields live in registers, the 16 activation values of
+  // a 32x32 tile are requested together (clamped addresses), stores are predicated.  (Written element by element with
+  // `continue`s, every H load was waited for before the next one was issued: 128 dependent round trips per thread.)
   float* C = P.C + (int64_t)z * P.slab_stride;
+  const int Mrows = P.M, Ncols = P.N, ldc = P.ldc, ldh = P.ldh, act = P.act;
+  const bool amask = P.epi == EPI_ACTMASK;
+  const bool dropon = P.drop_on != 0;
+  const float dscale = dropon ? P.drop.scale : 1.f;
+  const float* Hp = P.H;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int col = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
-      if (col >= P.N) continue;
+      const int rbase = m0 + wm * (MI * 32) + i * 32 + 4 * (lane >> 5);
+      const bool cok = col < Ncols;
+      const int colc = cok ? col : 0;
+      float hv[16];
+      if (amask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          hv[r] = Hp[(int64_t)(row < Mrows ? row : Mrows - 1) * ldh + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= P.M) continue;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
         float v = acc[i][j][r];
-        if (P.epi == EPI_ACTMASK) {
-          const float h = P.H[(int64_t)row * P.ldh + col];
-          const bool keep = !P.drop_on || (__float_as_uint(h) != 0x80000000u);  // dropped elements were stored as -0.0f
-          v *= bf_act_mask(h, P.act, keep, P.drop_on ? P.drop.scale : 1.f);
+        if (amask) {
+          const bool keep = !dropon || (__float_as_uint(hv[r]) != 0x80000000u);  // dropped elements were stored as -0.0f
+          v *= bf_act_mask(hv[r], act, keep, dscale);
         }
-        C[(int64_t)row * P.ldc + col] = v;
+        if (cok && row < Mrows) C[(int64_t)row * ldc + col] = v;
       }
     }
   if (ONES && ones_here && (lane & 31) == 0) {  // column 0 of the ones product -> C[:, n_real]
@@ -325,10 +368,28 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
   }
   gb.total_tiles = start;
   if (start == 0) return HMP_OK;
-  if (big && any_ones) hipLaunchKernelGGL((gemm_bf16_kernel<true, 512, 256, 4, 2, 32>), dim3(start), dim3(512), 0, st, gb);
-  else if (big) hipLaunchKernelGGL((gemm_bf16_kernel<false, 512, 256, 4, 2, 32>), dim3(start), dim3(512), 0, st, gb);
-  else if (any_ones) hipLaunchKernelGGL((gemm_bf16_kernel<true, 256, 128, 2, 2, 64>), dim3(start), dim3(256), 0, st, gb);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<false, 256, 128, 2, 2, 64>), dim3(start), dim3(256), 0, st, gb);
+  // operand form shared by every problem of the launch (the executor's launches are uniform), else the run-time variant
+  int form = -1;
+  for (int i = 0; i < gb.n; ++i) {
+    const GemmProblem& p = gb.p[i];
+    const int f = (!p.trans_a && p.trans_b) ? 0 : (!p.trans_a && !p.trans_b) ? 1 : (p.trans_a && !p.trans_b) ? 2 : 3;
+    form = (form == -1 || form == f) ? f : 3;
+  }
+#define BF_LAUNCH(ONES_, NT_, ROWS_, WM_, WN_, BK_, FORM_) \
+  hipLaunchKernelGGL((gemm_bf16_kernel<ONES_, NT_, ROWS_, WM_, WN_, BK_, FORM_>), dim3(start), dim3(NT_), 0, st, gb)
+#define BF_FORMS(ONES_, NT_, ROWS_, WM_, WN_, BK_)          \
+  switch (form) {                                           \
+    case 0: BF_LAUNCH(ONES_, NT_, ROWS_, WM_, WN_, BK_, 0); break; \
+    case 1: BF_LAUNCH(ONES_, NT_, ROWS_, WM_, WN_, BK_, 1); break; \
+    case 2: BF_LAUNCH(ONES_, NT_, ROWS_, WM_, WN_, BK_, 2); break; \
+    default: BF_LAUNCH(ONES_, NT_, ROWS_, WM_, WN_, BK_, 3); break; \
+  }
+  if (big && any_ones) { BF_FORMS(true, 512, 256, 4, 2, 32) }
+  else if (big) { BF_FORMS(false, 512, 256, 4, 2, 32) }
+  else if (any_ones) { BF_FORMS(true, 256, 128, 2, 2, 64) }
+  else { BF_FORMS(false, 256, 128, 2, 2, 64) }
+#undef BF_FORMS
+#undef BF_LAUNCH
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
