@@ -42,51 +42,58 @@ struct TileRegs {
 template <int ROWS, int BK, int VEC>
 __device__ __forceinline__ void tile_load_fast(TileRegs<ROWS, BK>& t, const float* __restrict__ p, int ld, int kcontig, int r0,
                                                int R, int k0, int kend) {
+  // ISSUES the loads only (clamped addresses); tile_mask zeroes what lies outside the operand when the stage is consumed, one
+  // iteration later -- a select on a loaded value right here makes the compiler wait for the load before the MFMAs it was
+  // meant to overlap with.
   constexpr int NV = TileRegs<ROWS, BK>::NV;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int q = tid + i * 256;
     const float* src;
-    bool m0, m1, m2, m3;
+    int o1 = 1, o2 = 2, o3 = 3;  // element offsets (VEC < 4: clamped so that no access leaves [.., kend))
     if (kcontig) {
       const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
       const int gr = r0 + r, gk = k0 + k4;
-      const bool rlive = gr < R;
-      m0 = rlive && gk + 0 < kend; m1 = rlive && gk + 1 < kend; m2 = rlive && gk + 2 < kend; m3 = rlive && gk + 3 < kend;
       // clamp: row to the last row; k to the start of the stage (always < kend) when the slot starts out of range
       const int gkc = (gk < kend) ? gk : k0;
-      src = p + (int64_t)(rlive ? gr : R - 1) * ld + gkc;
-      if (VEC == 1) {  // scalar rows may end right at kend: clamp every element
-        float e0 = src[0];
-        float e1 = src[(gk + 1 < kend) ? 1 : 0], e2 = src[(gk + 2 < kend) ? 2 : 0], e3 = src[(gk + 3 < kend) ? 3 : 0];
-        t.v[i] = make_float4(m0 ? e0 : 0.f, m1 ? e1 : 0.f, m2 ? e2 : 0.f, m3 ? e3 : 0.f);
-        continue;
-      }
-      if (VEC == 2) {  // the second pair may start at/after kend (possibly the end of the buffer): re-read the first pair then
-        const float2 a = *reinterpret_cast<const float2*>(src);
-        const float2 b = *reinterpret_cast<const float2*>(src + ((gk + 2 < kend) ? 2 : 0));
-        t.v[i] = make_float4(m0 ? a.x : 0.f, m1 ? a.y : 0.f, m2 ? b.x : 0.f, m3 ? b.y : 0.f);
-        continue;
-      }
+      src = p + (int64_t)(gr < R ? gr : R - 1) * ld + gkc;
+      if (VEC == 1) { o1 = (gkc + 1 < kend) ? 1 : 0; o2 = (gkc + 2 < kend) ? 2 : 0; o3 = (gkc + 3 < kend) ? 3 : 0; }
+      if (VEC == 2) { o2 = (gkc + 2 < kend) ? 2 : 0; }  // the second pair may start at / after kend: re-read the first pair then
     } else {
       const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
       const int gk = k0 + k;
-      const bool klive = gk < kend;
-      m0 = m1 = m2 = m3 = klive;
-      src = p + (int64_t)(klive ? gk : k0) * ld + (r0 + r4);
+      src = p + (int64_t)(gk < kend ? gk : k0) * ld + (r0 + r4);
     }
-    float4 val;
     if (VEC == 4) {
-      val = *reinterpret_cast<const float4*>(src);
+      t.v[i] = *reinterpret_cast<const float4*>(src);
     } else if (VEC == 2) {
       const float2 a = *reinterpret_cast<const float2*>(src);
-      const float2 b = *reinterpret_cast<const float2*>(src + 2);
-      val = make_float4(a.x, a.y, b.x, b.y);
+      const float2 b = *reinterpret_cast<const float2*>(src + o2);
+      t.v[i] = make_float4(a.x, a.y, b.x, b.y);
     } else {
-      val = make_float4(src[0], src[1], src[2], src[3]);
+      t.v[i] = make_float4(src[0], src[o1], src[o2], src[o3]);
     }
-    t.v[i] = make_float4(m0 ? val.x : 0.f, m1 ? val.y : 0.f, m2 ? val.z : 0.f, m3 ? val.w : 0.f);
+  }
+}
+
+template <int ROWS, int BK>
+__device__ __forceinline__ void tile_mask(TileRegs<ROWS, BK>& t, int kcontig, int r0, int R, int k0, int kend) {
+  constexpr int NV = TileRegs<ROWS, BK>::NV;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * 256;
+    if (kcontig) {
+      const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
+      const int gk = k0 + k4;
+      const bool rlive = r0 + r < R;
+      t.v[i] = make_float4(rlive && gk + 0 < kend ? t.v[i].x : 0.f, rlive && gk + 1 < kend ? t.v[i].y : 0.f,
+                           rlive && gk + 2 < kend ? t.v[i].z : 0.f, rlive && gk + 3 < kend ? t.v[i].w : 0.f);
+    } else {
+      const int k = q / (ROWS / 4);
+      if (k0 + k >= kend) t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -201,7 +208,9 @@ __device__ __forceinline__ int vec_mode(const float* p, int ld, bool k_ok) {
   return 1;
 }
 
-template <int WM, int WN, int BK>
+// FORM fixes the operand layouts at compile time (0: NT = x * W^T, 1: NN = dZ * W, 2: TN = dZ^T * [x | 1]; 3: per problem at run
+// time): with run-time layouts the layout branch sits inside the unrolled load loops and the loads stop overlapping.
+template <int WM, int WN, int BK, int FORM>
 // second launch-bound = waves per SIMD = blocks per CU for 256-thread blocks: >= 3 so that the ~600 workgroups of an MP3D
 // layer-0 projection are all resident at once (one round instead of two)
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
@@ -232,8 +241,11 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
   const int kbeg = z * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
 
-  const int a_kcontig = P.trans_a ? 0 : 1;
-  const int b_kcontig = P.trans_b ? 1 : 0;
+  const int a_kcontig = FORM == 3 ? (P.trans_a ? 0 : 1) : (FORM == 2 ? 0 : 1);
+  const int b_kcontig = FORM == 3 ? (P.trans_b ? 1 : 0) : (FORM == 0 ? 1 : 0);
+  // fast (clamp + deferred mask) or edge (bounds-checked, final values) loader per operand; block-uniform
+  const bool a_fast = a_kcontig || (m0 + BM <= P.M);
+  const bool b_fast = b_kcontig || (n0 + BN <= P.n_real);
   // kbeg is a multiple of BK (>= 32), so k offsets keep the row alignment class
   const int a_vec = vec_mode(P.A, P.lda, true);
   const int b_vec = vec_mode(P.B, P.ldb, true);
@@ -255,6 +267,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
   int kti = 0;
   (void)kti;
   for (int kt = kbeg; kt < kend; kt += BK) {
+    if (a_fast) tile_mask<BM, BK>(ra, a_kcontig, m0, P.M, kt, kend);
+    if (b_fast) tile_mask<BN, BK>(rb, b_kcontig, n0, P.n_real, kt, kend);
     tile_store<BM, BK>(ra, As, a_kcontig);
     tile_store<BN, BK>(rb, Bs, b_kcontig);
     __syncthreads();
@@ -310,21 +324,35 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
 
   // A = [i][k] supplies the rows of C, B = [k][j] its columns;
   // D layout: col j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // No branch between memory operations: fields in registers, the 16 activation values requested together (clamped addresses),
+  // predicated stores.  (With a `continue` per element the compiler waited for every H load before issuing the next one.)
   float* C = P.C + (int64_t)z * P.slab_stride;
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= P.N) return;
+  const int Mrows = P.M, ldc = P.ldc, ldh = P.ldh, act = P.act;
+  const bool amask = P.epi == EPI_ACTMASK;
+  const bool dropon = P.drop_on != 0;
+  const float dscale = dropon ? P.drop.scale : 1.f;
+  const float* Hp = P.H;
+  const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
+  float hv[16];
+  if (amask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      hv[r] = Hp[(int64_t)(row < Mrows ? row : Mrows - 1) * ldh + col];
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row >= P.M) continue;
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
     float v = acc[r];
-    if (P.epi == EPI_ACTMASK) {
-      const float h = P.H[(int64_t)row * P.ldh + col];
+    if (amask) {
       // the forward stored dropped elements as -0.0f: the keep bit is the sign of a zero, no RNG replay needed
-      const bool keep = !P.drop_on || (__float_as_uint(h) != 0x80000000u);
-      v *= act_mask_factor(h, P.act, keep, P.drop_on ? P.drop.scale : 1.f);
+      const bool keep = !dropon || (__float_as_uint(hv[r]) != 0x80000000u);
+      v *= act_mask_factor(hv[r], act, keep, dscale);
     }
-    C[(int64_t)row * P.ldc + col] = v;
+    if (row < Mrows) C[(int64_t)row * ldc + col] = v;
   }
   KT(9);
 }
@@ -360,7 +388,19 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
   }
   gb.total_tiles = start;
   if (start == 0) return HMP_OK;
-  hipLaunchKernelGGL((gemm_kernel<WM, WN, BK>), dim3(start), dim3(256), 0, st, gb);
+  // operand form shared by every problem of the launch (the executor's launches are uniform), else the run-time variant
+  int form = -1;
+  for (int i = 0; i < gb.n; ++i) {
+    const GemmProblem& p = gb.p[i];
+    const int f = (!p.trans_a && p.trans_b) ? 0 : (!p.trans_a && !p.trans_b) ? 1 : (p.trans_a && !p.trans_b) ? 2 : 3;
+    form = (form == -1 || form == f) ? f : 3;
+  }
+  switch (form) {
+    case 0: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 0>), dim3(start), dim3(256), 0, st, gb); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 1>), dim3(start), dim3(256), 0, st, gb); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 2>), dim3(start), dim3(256), 0, st, gb); break;
+    default: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 3>), dim3(start), dim3(256), 0, st, gb); break;
+  }
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
