@@ -29,7 +29,17 @@ namespace {
 
 constexpr float NEG_SLOPE = 0.2f;
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// The descriptors live in a device-memory table, so the pointers they hold are GENERIC to the compiler: it would emit
+// flat_load (counted on vmcnt AND lgkmcnt, i.e. every wait drains everything).  gp() tells it they are global.
+template <typename T>
+using gptr = const T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ gptr<T> gp(const T* p) { return (gptr<T>)p; }
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) {
+  const f4v v = *(gptr<f4v>)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
   a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
 }
@@ -76,37 +86,51 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 template <int HM>
 __device__ __forceinline__ void edge_logits(const GatInS& I, const float* ea, int H, const float* aj, const float (&ad)[HM],
                                             const float (&ve)[GAT_MAX_EDIM][HM], bool use, int eid, float (&raw)[HM]) {
+  // every load is unconditional (head / attribute index clamped into range, the value masked afterwards): a load under a
+  // run-time `h < H` is a branch, and the compiler then waits for each load before it issues the next one
   float x[GAT_MAX_EDIM] = {0.f, 0.f, 0.f, 0.f};
   if (ea) {  // uniform
 #pragma unroll
-    for (int d = 0; d < GAT_MAX_EDIM; ++d)
-      if (d < I.edim) {
-        const float t = ea[(int64_t)eid * I.edim + d];
-        x[d] = use ? t : 0.f;
-      }
+    for (int d = 0; d < GAT_MAX_EDIM; ++d) {
+      const float t = gp(ea)[(int64_t)eid * I.edim + min(d, I.edim - 1)];
+      x[d] = (use && d < I.edim) ? t : 0.f;
+    }
   }
+  float as[HM];
+#pragma unroll
+  for (int h = 0; h < HM; ++h) as[h] = gp(aj)[I.asoff + min(h, H - 1)];
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
-    float r = 0.f;
-    if (h < H) {
-      r = aj[I.asoff + h] + ad[h];
-      if (ea) {
+    float r = as[h] + ad[h];
+    if (ea) {
 #pragma unroll
-        for (int d = 0; d < GAT_MAX_EDIM; ++d) r += x[d] * ve[d][h];
-      }
+      for (int d = 0; d < GAT_MAX_EDIM; ++d) r += x[d] * ve[d][h];
     }
-    raw[h] = r;
+    raw[h] = h < H ? r : 0.f;
   }
 }
 
 template <int HM>
 __device__ __forceinline__ void load_row_consts(const GatInS& I, int H, int row, float (&ad)[HM], float (&ve)[GAT_MAX_EDIM][HM]) {
 #pragma unroll
-  for (int h = 0; h < HM; ++h) ad[h] = (h < H) ? I.zd[(int64_t)row * I.ldzd + I.adoff + h] : 0.f;
+  for (int h = 0; h < HM; ++h) {
+    const float t = gp(I.zd)[(int64_t)row * I.ldzd + I.adoff + min(h, H - 1)];
+    ad[h] = (h < H) ? t : 0.f;
+  }
+  if (I.vedge && I.edim > 0) {  // uniform
 #pragma unroll
-  for (int d = 0; d < GAT_MAX_EDIM; ++d)
+    for (int d = 0; d < GAT_MAX_EDIM; ++d)
 #pragma unroll
-    for (int h = 0; h < HM; ++h) ve[d][h] = (I.vedge && d < I.edim && h < H) ? I.vedge[d * GAT_HMAX + h] : 0.f;
+      for (int h = 0; h < HM; ++h) {
+        const float t = gp(I.vedge)[min(d, I.edim - 1) * GAT_HMAX + min(h, H - 1)];
+        ve[d][h] = (d < I.edim && h < H) ? t : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int d = 0; d < GAT_MAX_EDIM; ++d)
+#pragma unroll
+      for (int h = 0; h < HM; ++h) ve[d][h] = 0.f;
+  }
 }
 
 // A batch of UB consecutive neighbour slots k0 .. k0+UB-1 of one destination row (real edges [b, e), then the virtual self
@@ -133,8 +157,8 @@ __device__ __forceinline__ void fetch_batch(const GatInS& I, int Cp, const float
     const bool in = k < kend;
     const bool lp = in && k >= e;
     const int kc = (e > b) ? min(k, e - 1) : 0;
-    const int cj = I.col[kc];
-    const int ce = ea ? I.eid[kc] : 0;
+    const int cj = gp(I.col)[kc];
+    const int ce = ea ? gp(I.eid)[kc] : 0;
     const bool real = in && !lp;
     B.loop[u] = lp;
     B.j[u] = lp ? row : (real ? cj : 0);  // dead slots read row 0 (always allocated), never used
@@ -147,7 +171,7 @@ __device__ __forceinline__ void fetch_batch(const GatInS& I, int Cp, const float
     edge_logits<HM>(I, ea, H, I.za + (int64_t)B.j[u] * I.ldza, ad, ve, !B.loop[u] && B.live[u], B.eid[u], B.raw[u]);
     const float* zj = I.z + (int64_t)B.j[u] * I.ldz + I.hoff + cc;
 #pragma unroll
-    for (int h = 0; h < HM; ++h) B.v[u][h] = (h < H) ? ld4(zj + h * Cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < HM; ++h) B.v[u][h] = ld4(zj + min(h, H - 1) * Cp);  // heads >= H: a duplicate nobody reads
   }
 }
 
