@@ -30,11 +30,11 @@ namespace {
 constexpr float NEG_SLOPE = 0.2f;
 
 // The descriptors live in a device-memory table, so the pointers they hold are GENERIC to the compiler: it would emit
-// flat_load (counted on vmcnt AND lgkmcnt, i.e. every wait drains everything).  gp() tells it they are global.
+// flat_load (counted on vmcnt AND lgkmcnt, i.e. every wait drains everything).  glob() tells it they are global.
 template <typename T>
 using gptr = const T __attribute__((address_space(1)))*;
 template <typename T>
-__device__ __forceinline__ gptr<T> gp(const T* p) { return (gptr<T>)p; }
+__device__ __forceinline__ gptr<T> glob(const T* p) { return (gptr<T>)p; }
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4(const float* p) {
   const f4v v = *(gptr<f4v>)p;
@@ -92,13 +92,13 @@ __device__ __forceinline__ void edge_logits(const GatInS& I, const float* ea, in
   if (ea) {  // uniform
 #pragma unroll
     for (int d = 0; d < GAT_MAX_EDIM; ++d) {
-      const float t = gp(ea)[(int64_t)eid * I.edim + min(d, I.edim - 1)];
+      const float t = glob(ea)[(int64_t)eid * I.edim + min(d, I.edim - 1)];
       x[d] = (use && d < I.edim) ? t : 0.f;
     }
   }
   float as[HM];
 #pragma unroll
-  for (int h = 0; h < HM; ++h) as[h] = gp(aj)[I.asoff + min(h, H - 1)];
+  for (int h = 0; h < HM; ++h) as[h] = glob(aj)[I.asoff + min(h, H - 1)];
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
     float r = as[h] + ad[h];
@@ -114,7 +114,7 @@ template <int HM>
 __device__ __forceinline__ void load_row_consts(const GatInS& I, int H, int row, float (&ad)[HM], float (&ve)[GAT_MAX_EDIM][HM]) {
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
-    const float t = gp(I.zd)[(int64_t)row * I.ldzd + I.adoff + min(h, H - 1)];
+    const float t = glob(I.zd)[(int64_t)row * I.ldzd + I.adoff + min(h, H - 1)];
     ad[h] = (h < H) ? t : 0.f;
   }
   if (I.vedge && I.edim > 0) {  // uniform
@@ -122,7 +122,7 @@ __device__ __forceinline__ void load_row_consts(const GatInS& I, int H, int row,
     for (int d = 0; d < GAT_MAX_EDIM; ++d)
 #pragma unroll
       for (int h = 0; h < HM; ++h) {
-        const float t = gp(I.vedge)[min(d, I.edim - 1) * GAT_HMAX + min(h, H - 1)];
+        const float t = glob(I.vedge)[min(d, I.edim - 1) * GAT_HMAX + min(h, H - 1)];
         ve[d][h] = (d < I.edim && h < H) ? t : 0.f;
       }
   } else {
@@ -157,8 +157,8 @@ __device__ __forceinline__ void fetch_batch(const GatInS& I, int Cp, const float
     const bool in = k < kend;
     const bool lp = in && k >= e;
     const int kc = (e > b) ? min(k, e - 1) : 0;
-    const int cj = gp(I.col)[kc];
-    const int ce = ea ? gp(I.eid)[kc] : 0;
+    const int cj = glob(I.col)[kc];
+    const int ce = ea ? glob(I.eid)[kc] : 0;
     const bool real = in && !lp;
     B.loop[u] = lp;
     B.j[u] = lp ? row : (real ? cj : 0);  // dead slots read row 0 (always allocated), never used
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
 #pragma unroll
     for (int h = 0; h < HM; ++h) { m[h] = -INFINITY; s[h] = 0.f; acc[h] = make_float4(0.f, 0.f, 0.f, 0.f); }
 
-    const int b = I.rowptr[row], e = I.rowptr[row + 1];
+    const int b = glob(I.rowptr)[row], e = glob(I.rowptr)[row + 1];
     const int kend = e + ((row < n_loop) ? 1 : 0);
     constexpr int UB = (HM <= 4) ? 4 : 2;
     const int cc = cact ? c0 : 0;
@@ -304,11 +304,27 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
 //   d e_k = alpha_k (d alpha_k - sum_k' alpha_k' d alpha_k'),  d raw_k = d e_k * leaky'(raw_k)
 // writes alpha'_k and d raw_k per edge (CSR position; loops at E + i), d a_dst[i,h] = sum_k d raw_k.
 // =================================================================================================
+// gradient slice of this lane for every head.  Vector path (C % 4 == 0, 16-byte aligned rows -- the executor's buffers):
+// one unconditional 16-byte load per head, head index clamped; otherwise element by element.
 template <int HM>
 __device__ __forceinline__ void load_g(const GatDstS& D, const GatDyn& dyn, int row, int c0, bool cact, float4 (&g)[HM]) {
   const float* gp = D.g ? D.g : dyn.g_top;
   const int ldg = D.g ? D.ldg : dyn.ld_gtop;
   const float* gr = gp + (int64_t)row * ldg;
+  const bool vec = (D.C & 3) == 0 && (ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(gp) & 15) == 0;  // uniform
+  const float sc = D.concat ? D.group_scale : D.group_scale / (float)D.H;
+  if (vec) {
+    const int cc = cact ? c0 : 0;
+#pragma unroll
+    for (int h = 0; h < HM; ++h) {
+      const float4 t = ld4(gr + (D.concat ? min(h, D.H - 1) * D.C : 0) + cc);
+      const bool on = cact && h < D.H;
+      g[h] = D.concat ? make_float4(on ? t.x * sc : 0.f, on ? t.y * sc : 0.f, on ? t.z * sc : 0.f, on ? t.w * sc : 0.f)
+                      : make_float4(on ? t.x / (float)D.H * D.group_scale : 0.f, on ? t.y / (float)D.H * D.group_scale : 0.f,
+                                    on ? t.z / (float)D.H * D.group_scale : 0.f, on ? t.w / (float)D.H * D.group_scale : 0.f);
+    }
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < HM; ++h) {
     float t4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -350,13 +366,13 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
     load_row_consts<HM>(I, H, row, ad, ve);
 #pragma unroll
     for (int h = 0; h < HM; ++h) {
-      m[h] = (h < H) ? I.smax[(int64_t)row * GAT_HMAX + h] : 0.f;
-      den[h] = (h < H) ? I.sden[(int64_t)row * GAT_HMAX + h] : 1.f;
+      m[h] = glob(I.smax)[(int64_t)row * GAT_HMAX + min(h, H - 1)];  // heads >= H: a duplicate nobody reads
+      den[h] = glob(I.sden)[(int64_t)row * GAT_HMAX + min(h, H - 1)];
     }
     const bool adrop = dyn.training && I.adrop_p > 0.f;
     DropCfg acfg;
     if (adrop) acfg = make_cfg(dyn, I.adrop_p, I.adrop_stream);
-    const int b = I.rowptr[row], e = I.rowptr[row + 1];
+    const int b = glob(I.rowptr)[row], e = glob(I.rowptr)[row + 1];
     const int kend = e + ((row < n_loop) ? 1 : 0);
 
     float tsum[HM], dsum[HM];
@@ -525,10 +541,13 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
     float das[HM];
 #pragma unroll
     for (int h = 0; h < HM; ++h) { acc[h] = make_float4(0.f, 0.f, 0.f, 0.f); das[h] = 0.f; }
-    const int b = I.t_rowptr[row], e = I.t_rowptr[row + 1];
+    const int b = glob(I.t_rowptr)[row], e = glob(I.t_rowptr)[row + 1];
     const int kend = e + ((row < n_loop) ? 1 : 0);
+    // vector path for the gradient rows (C % 4 == 0, 16-byte aligned rows: the executor's buffers); uniform
+    const bool vec = (D.C & 3) == 0 && (ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(gp) & 15) == 0;
+    const int cc = cact ? c0 : 0;
     // out-edges in batches of 4: destination ids + CSR positions first, then the per-edge scalars and gradient rows of the
-    // whole batch in flight together; the adds keep the edge order
+    // whole batch in flight together (all loads unconditional: head index clamped, see edge_logits); the adds keep the edge order
     constexpr int UB = (HM <= 4) ? 4 : 2;
     for (int k0 = b; k0 < kend; k0 += UB) {
       int ii[UB];
@@ -540,8 +559,8 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
         in[u] = k < kend;
         const bool lp = in[u] && k >= e;
         const int kc = (e > b) ? min(k, e - 1) : 0;
-        const int ti = I.t_col[kc];
-        const int tp = I.t_pos[kc];
+        const int ti = glob(I.t_col)[kc];
+        const int tp = glob(I.t_pos)[kc];
         const bool real = in[u] && !lp;
         ii[u] = lp ? row : (real ? ti : 0);
         pp[u] = lp ? (E + row) : (real ? (int64_t)tp : 0);
@@ -553,17 +572,26 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
         const float* gr = gp + (int64_t)ii[u] * ldg;
 #pragma unroll
         for (int h = 0; h < HM; ++h) {
-          ap[u][h] = (h < H) ? I.alpha_drop[pp[u] * GAT_HMAX + h] : 0.f;
-          dl[u][h] = (h < H) ? I.dlogit[pp[u] * GAT_HMAX + h] : 0.f;
-          float t4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (cact && h < H && (D.concat || h == 0)) {
+          const int hc = min(h, H - 1);
+          ap[u][h] = glob(I.alpha_drop)[pp[u] * GAT_HMAX + hc];
+          dl[u][h] = glob(I.dlogit)[pp[u] * GAT_HMAX + hc];
+        }
+        if (vec) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = c0 + q;
-              if (c < D.C) t4[q] = D.concat ? gr[h * D.C + c] : gr[c];
+          for (int h = 0; h < HM; ++h) gv[u][h] = ld4(gr + (D.concat ? min(h, H - 1) * D.C : 0) + cc);
+        } else {
+#pragma unroll
+          for (int h = 0; h < HM; ++h) {
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (cact && h < H && (D.concat || h == 0)) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q;
+                if (c < D.C) t4[q] = D.concat ? gr[h * D.C + c] : gr[c];
+              }
             }
+            gv[u][h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
           }
-          gv[u][h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
       }
 #pragma unroll
