@@ -31,11 +31,20 @@ constexpr float NEG_SLOPE = 0.2f;
 
 // The descriptors live in a device-memory table, so the pointers they hold are GENERIC to the compiler: it would emit
 // flat_load (counted on vmcnt AND lgkmcnt, i.e. every wait drains everything).  glob() tells it they are global.
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <typename T>
 using gptr = const T __attribute__((address_space(1)))*;
 template <typename T>
 __device__ __forceinline__ gptr<T> glob(const T* p) { return (gptr<T>)p; }
-typedef float f4v __attribute__((ext_vector_type(4)));
+template <typename T>
+using gwptr = T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ gwptr<T> globw(T* p) { return (gwptr<T>)p; }
+__device__ __forceinline__ void st4(float* p, const float4& v) {
+  f4v t;
+  t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  *(gwptr<f4v>)p = t;
+}
 __device__ __forceinline__ float4 ld4(const float* p) {
   const f4v v = *(gptr<f4v>)p;
   return make_float4(v[0], v[1], v[2], v[3]);
@@ -251,8 +260,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
       const float den = s[h] + 1e-16f;
       tot[h].x += acc[h].x / den; tot[h].y += acc[h].y / den; tot[h].z += acc[h].z / den; tot[h].w += acc[h].w / den;
       if (gl == 0) {
-        I.smax[(int64_t)row * GAT_HMAX + h] = m[h];
-        I.sden[(int64_t)row * GAT_HMAX + h] = den;
+        globw(I.smax)[(int64_t)row * GAT_HMAX + h] = m[h];
+        globw(I.sden)[(int64_t)row * GAT_HMAX + h] = den;
       }
     }
   }
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
   DropCfg fcfg;
   if (fdrop) fcfg = make_cfg(dyn, D.drop_p, D.drop_stream);
   auto finish = [&](float v, int col) -> float {
-    v = (v + (D.bias ? D.bias[col] : 0.f)) * D.group_scale;
+    v = (v + (D.bias ? glob(D.bias)[col] : 0.f)) * D.group_scale;
     v = act_apply(v, D.act);
     if (fdrop) {
       bool k4[4];
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatLayerS* __restric
     }
     return v;
   };
-  float* orow = D.out + (int64_t)row * D.ldo;
+  auto orow = globw(D.out) + (int64_t)row * D.ldo;
   if (D.concat) {
 #pragma unroll
     for (int h = 0; h < HM; ++h) {
@@ -332,7 +341,7 @@ __device__ __forceinline__ void load_g(const GatDstS& D, const GatDyn& dyn, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = c0 + i;
-        if (c < D.C) t4[i] = D.concat ? gr[h * D.C + c] : gr[c] / (float)D.H;
+        if (c < D.C) t4[i] = D.concat ? glob(gr)[h * D.C + c] : glob(gr)[c] / (float)D.H;
       }
     }
     g[h] = make_float4(t4[0] * D.group_scale, t4[1] * D.group_scale, t4[2] * D.group_scale, t4[3] * D.group_scale);
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
         const int k = b + idx;
         const bool is_loop = k >= e;
         const int64_t pos = is_loop ? (E + row) : (int64_t)k;
-        const int eo = (I.dlogit_orig && !is_loop) ? I.eid[k] : 0;
+        const int eo = (I.dlogit_orig && !is_loop) ? glob(I.eid)[k] : 0;
 #pragma unroll
         for (int h = 0; h < HM; ++h) {
           if (h >= H) continue;
@@ -451,9 +460,9 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
             apd = alpha * crow[idx][h][3];
             dpart[h] += dl;
           }
-          I.alpha_drop[pos * GAT_HMAX + h] = apd;
-          I.dlogit[pos * GAT_HMAX + h] = dl;
-          if (I.dlogit_orig && !is_loop) I.dlogit_orig[(int64_t)eo * GAT_HMAX + h] = dl;
+          globw(I.alpha_drop)[pos * GAT_HMAX + h] = apd;
+          globw(I.dlogit)[pos * GAT_HMAX + h] = dl;
+          if (I.dlogit_orig && !is_loop) globw(I.dlogit_orig)[(int64_t)eo * GAT_HMAX + h] = dl;
         }
       }
 #pragma unroll
@@ -471,9 +480,9 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
 #pragma unroll
             for (int h = 0; h < HM; ++h)
               if (h < H) {
-                I.alpha_drop[pos * GAT_HMAX + h] = 0.f;
-                I.dlogit[pos * GAT_HMAX + h] = 0.f;
-                if (I.dlogit_orig) I.dlogit_orig[(int64_t)I.eid[k] * GAT_HMAX + h] = 0.f;
+                globw(I.alpha_drop)[pos * GAT_HMAX + h] = 0.f;
+                globw(I.dlogit)[pos * GAT_HMAX + h] = 0.f;
+                if (I.dlogit_orig) globw(I.dlogit_orig)[(int64_t)glob(I.eid)[k] * GAT_HMAX + h] = 0.f;
               }
           }
           continue;
@@ -498,9 +507,9 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
           const float dl = de * (rw > 0.f ? 1.f : NEG_SLOPE);
           dsum[h] += dl;
           if (gl == 0) {
-            I.alpha_drop[pos * GAT_HMAX + h] = alpha * dscale;
-            I.dlogit[pos * GAT_HMAX + h] = dl;
-            if (I.dlogit_orig && !B.loop[u]) I.dlogit_orig[(int64_t)B.eid[u] * GAT_HMAX + h] = dl;
+            globw(I.alpha_drop)[pos * GAT_HMAX + h] = alpha * dscale;
+            globw(I.dlogit)[pos * GAT_HMAX + h] = dl;
+            if (I.dlogit_orig && !B.loop[u]) globw(I.dlogit_orig)[(int64_t)B.eid[u] * GAT_HMAX + h] = dl;
           }
         }
       }
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restri
     if (gl == 0) {
 #pragma unroll
       for (int h = 0; h < HM; ++h)
-        if (h < H) I.dz_dst[(int64_t)row * I.lddz_dst + I.adoff + h] = dsum[h];
+        if (h < H) globw(I.dz_dst)[(int64_t)row * I.lddz_dst + I.adoff + h] = dsum[h];
     }
     KT(4 + 4 * ii);
   }
@@ -573,8 +582,8 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
 #pragma unroll
         for (int h = 0; h < HM; ++h) {
           const int hc = min(h, H - 1);
-          ap[u][h] = glob(I.alpha_drop)[pp[u] * GAT_HMAX + hc];
-          dl[u][h] = glob(I.dlogit)[pp[u] * GAT_HMAX + hc];
+          ap[u][h] = globw(I.alpha_drop)[pp[u] * GAT_HMAX + hc];
+          dl[u][h] = globw(I.dlogit)[pp[u] * GAT_HMAX + hc];
         }
         if (vec) {
 #pragma unroll
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const int c = c0 + q;
-                if (c < D.C) t4[q] = D.concat ? gr[h * D.C + c] : gr[c];
+                if (c < D.C) t4[q] = D.concat ? glob(gr)[h * D.C + c] : glob(gr)[c];
               }
             }
             gv[u][h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
@@ -618,8 +627,8 @@ __global__ __launch_bounds__(256) void gat_bwd2_kernel(const GatLayerS* __restri
 #pragma unroll
     for (int h = 0; h < HM; ++h) {
       if (h >= H) continue;
-      if (cact) *reinterpret_cast<float4*>(dzr + I.hoff + h * D.Cp + c0) = acc[h];
-      if (gl == 0) I.dza_src[(int64_t)row * I.lddza_src + I.asoff + h] = das[h];
+      if (cact) st4(dzr + I.hoff + h * D.Cp + c0, acc[h]);
+      if (gl == 0) globw(I.dza_src)[(int64_t)row * I.lddza_src + I.asoff + h] = das[h];
     }
   }
 }
