@@ -351,8 +351,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (32-row tiles -- half the per-row weight traffic, two MFMA row halves sharing each B load -- were measured SLOWER on the
 // H-tree config 4: 0.585 against 0.474 ms/step; half as many blocks, twice the gather passes per block.)
+// GS >= 32 (H-tree, hidden 128: ~1000 blocks of 16 rows): 4 waves per SIMD = 4 blocks per CU keeps the whole launch resident in
+// one round (measured 0.152 -> 0.140 ms over the 4 layers of config 4 despite 148 bytes of spill; the same bound made the
+// backward kernel slower and is not applied there)
 template <int GS>
-__global__ __launch_bounds__(256) void agg_proj_fwd_kernel(const AggArgs a) {
+__global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
   constexpr int TM = 16, LDH = 17;
   constexpr int RPP = 256 / GS;            // rows aggregated per pass
   constexpr int NP = TM / RPP;             // passes (GS = 16: 1, 32: 2, 64: 4)
