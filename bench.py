@@ -239,7 +239,10 @@ def main():
 
     model_kw, cls_name, batch_cpu, label_type, workload = make_workload(args, rank)
     torch.manual_seed(1234)  # identical initial weights on every rank
-    net = getattr(hmodels, cls_name)(**model_kw).to(dev)
+    import contextlib
+
+    with contextlib.redirect_stdout(sys.stderr):  # the H-tree constructors print like the reference's; stdout carries ONE JSON line
+        net = getattr(hmodels, cls_name)(**model_kw).to(dev)
     net.train()
     net.native().set_compute(args.precision)
     batch = batch_cpu.to(dev)
@@ -412,7 +415,8 @@ def main():
         cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         torch.set_num_threads(cores)
         torch.manual_seed(1234)
-        ora = getattr(omodels, cls_name)(**model_kw)
+        with contextlib.redirect_stdout(sys.stderr):
+            ora = getattr(omodels, cls_name)(**model_kw)
         ora.train()
         opt = torch.optim.Adam(ora.parameters(), lr=0.002, weight_decay=0.001)
         cpu_scale = 1.0
