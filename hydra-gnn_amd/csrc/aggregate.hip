@@ -326,7 +326,10 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   // workgroups go to the 8 XCDs round robin by block id: give XCD x the x-th contiguous eighth of the rows, so that the
   // neighbour rows a run of consecutive destinations shares (scene graphs: the same room) are fetched into ONE L2, not 8
   if (a.xcd) local = (local & 7) * ((cdiv_dev(D.n_rows, rpb) + 7) >> 3) + (local >> 3);
-  const int row = local * rpb + threadIdx.x / GS;
+  int row = local * rpb + threadIdx.x / GS;
+  // GS = 64: the wavefront IS the row group, so the row (and with it every extent / neighbour id) is wave-uniform; saying so
+  // moves those loads and the address arithmetic to the scalar unit
+  if (GS == 64) row = __builtin_amdgcn_readfirstlane(row);
   if (row >= D.n_rows) return;
   Acc<4> tot[NV];
   const int c0 = (threadIdx.x % GS) * 4;
@@ -468,7 +471,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   const int rpb = 256 / GS;
   int local = blockIdx.x - S.block_start;
   if (a.xcd) local = (local & 7) * ((cdiv_dev(S.n_rows, rpb) + 7) >> 3) + (local >> 3);  // see agg_fwd_kernel
-  const int row = local * rpb + threadIdx.x / GS;
+  int row = local * rpb + threadIdx.x / GS;
+  if (GS == 64) row = __builtin_amdgcn_readfirstlane(row);  // wave-uniform, see agg_fwd_kernel
   if (row >= S.n_rows) return;
   const int c0 = (threadIdx.x % GS) * VEC;
   int rb[AGG_MAX_IN], re[AGG_MAX_IN];
