@@ -192,7 +192,53 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
     rb[ii] = re[ii] = 0;
     if (ii < D.n_in) { rb[ii] = D.in[ii].rowptr[row]; re[ii] = D.in[ii].rowptr[row + 1]; }
   }
-  if constexpr (NV == 1) {
+  if constexpr (NV == 1 && GS == 64) {
+    // One wavefront per row (the caller made `row` wave-uniform): the neighbour ids of BOTH edge types of a pair are scalar
+    // loads issued together, then 16 rows of the first type in flight, then 16 of the second through the same registers --
+    // extents, ids, rows, rows: 4 dependent round trips for in-degrees <= 16 (the 8 + 8 pair batch needed a tail pass from 9
+    // neighbours on) and no clamped duplicate loads for the short list of a pair (rooms -> objects: one neighbour).
+    constexpr int UB = 16;
+    const bool cin = c0 < D.F;
+    const int cc = cin ? c0 : 0;
+#pragma unroll
+    for (int ii = 0; ii < AGG_MAX_IN; ii += 2) {
+      if (ii >= D.n_in) break;
+      const bool has2 = ii + 1 < D.n_in;
+      const AggIn& I0 = D.in[ii];
+      const AggIn& I1 = D.in[has2 ? ii + 1 : ii];
+      const int b0 = rb[ii], e0 = re[ii];
+      const int b1 = has2 ? rb[ii + 1] : b0, e1 = has2 ? re[ii + 1] : b0;
+      int j0[UB], j1[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        j0[u] = I0.col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
+        j1[u] = I1.col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+      }
+      Acc<VEC> v[UB], a0[1], a1[1];
+      a0[0].zero();
+      a1[0].zero();
+      if (e0 > b0) {  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < UB; ++u) v[u].load(I0.z + I0.coff + (int64_t)j0[u] * I0.ldz + cc);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (b0 + u < e0) a0[0].add(v[u]);
+      }
+      if (e1 > b1) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) v[u].load(I1.z + I1.coff + (int64_t)j1[u] * I1.ldz + cc);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (b1 + u < e1) a1[0].add(v[u]);
+      }
+      if (e0 - b0 > UB) gather_sum<GS, 1, VEC>(a0, I0.z + I0.coff, I0.ldz, I0.col, b0 + UB, e0, c0, D.F);
+      if (e1 - b1 > UB) gather_sum<GS, 1, VEC>(a1, I1.z + I1.coff, I1.ldz, I1.col, b1 + UB, e1, c0, D.F);
+      if (cin) {
+        if (e0 > b0) tot[0].add_div(a0[0], mean ? (float)(e0 - b0) : 1.f);
+        if (e1 > b1) tot[0].add_div(a1[0], mean ? (float)(e1 - b1) : 1.f);
+      }
+    }
+  } else if constexpr (NV == 1) {
     // Incoming edge types in PAIRS: the neighbour ids of both types travel together, then the 16 neighbour rows -- three
     // dependent round trips (extents, ids, rows) for two edge types instead of five.  A missing partner aliases the
     // first type with an empty extent (loads hit the same lines, adds are masked).  Sums keep the edge order per type
@@ -481,6 +527,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
     rb[oi] = re[oi] = 0;
     if (oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
   }
+  // (the 16-wide scalar-id form of agg_row was measured here too: 6.94 -> 7.02 ms at config 5, not kept)
   if constexpr (NV == 1) {
     // outgoing edge types in PAIRS (see agg_row): ids of both, then 1/deg + gradient rows of both
     constexpr int UB = 8;
