@@ -252,11 +252,20 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
       const AggIn& I1 = D.in[has2 ? ii + 1 : ii];
       const int b0 = rb[ii], e0 = re[ii];
       const int b1 = has2 ? rb[ii + 1] : b0, e1 = has2 ? re[ii + 1] : b0;
-      int j0[UB], j1[UB];
+      // GS <= 16 (rows of <= 64 floats, the MP3D hidden width): ids of neighbours 0..7 AND 8..15 of both types in the same round
+      // trip -- a row of 9..16 neighbours (most 16-row blocks of a scene-graph batch hold one) then needs one more round trip
+      // for its second batch of rows instead of two.  Wider rows keep the plain tail: the 16 extra registers cost them a wave
+      // per SIMD (config 4: 0.140 -> 0.151 ms).
+      constexpr bool PRE = GS <= 16;
+      int j0[UB], j1[UB], j0t[PRE ? UB : 1], j1t[PRE ? UB : 1];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         j0[u] = I0.col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
         j1[u] = I1.col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+        if constexpr (PRE) {
+          j0t[u] = I0.col[e0 > b0 ? min(b0 + UB + u, e0 - 1) : 0];
+          j1t[u] = I1.col[e1 > b1 ? min(b1 + UB + u, e1 - 1) : 0];
+        }
       }
       Acc<VEC> v0[UB], v1[UB];
       const bool cin = c0 < D.F;
@@ -275,8 +284,25 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
 #pragma unroll
       for (int u = 0; u < UB; ++u)
         if (b1 + u < e1) a1[0].add(v1[u]);
-      if (e0 - b0 > UB) gather_sum<GS, 1, VEC>(a0, I0.z + I0.coff, I0.ldz, I0.col, b0 + UB, e0, c0, D.F);
-      if (e1 - b1 > UB) gather_sum<GS, 1, VEC>(a1, I1.z + I1.coff, I1.ldz, I1.col, b1 + UB, e1, c0, D.F);
+      int done = UB;
+      if constexpr (PRE) {
+        if (e0 - b0 > UB || e1 - b1 > UB) {  // second batch through the same registers (ids already here)
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            v0[u].load(I0.z + I0.coff + (int64_t)j0t[u] * I0.ldz + cc);
+            v1[u].load(I1.z + I1.coff + (int64_t)j1t[u] * I1.ldz + cc);
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (b0 + UB + u < e0) a0[0].add(v0[u]);
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (b1 + UB + u < e1) a1[0].add(v1[u]);
+        }
+        done = 2 * UB;
+      }
+      if (e0 - b0 > done) gather_sum<GS, 1, VEC>(a0, I0.z + I0.coff, I0.ldz, I0.col, b0 + done, e0, c0, D.F);
+      if (e1 - b1 > done) gather_sum<GS, 1, VEC>(a1, I1.z + I1.coff, I1.ldz, I1.col, b1 + done, e1, c0, D.F);
       if (cin) {
         if (e0 > b0) tot[0].add_div(a0[0], mean ? (float)(e0 - b0) : 1.f);
         if (e1 > b1) tot[0].add_div(a1[0], mean ? (float)(e1 - b1) : 1.f);
@@ -539,11 +565,17 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       const TAggOut& O1 = S.out[has2 ? oi + 1 : oi];
       const int b0 = rb[oi], e0 = re[oi];
       const int b1 = has2 ? rb[oi + 1] : b0, e1 = has2 ? re[oi + 1] : b0;
-      int i0[UB], i1[UB];
+      // GS <= 16: the ids of out-edges 8..15 travel with those of 0..7 (see agg_row): one round trip less for rows of 9..16 edges
+      constexpr bool PRE = GS <= 16;
+      int i0[UB], i1[UB], i0t[PRE ? UB : 1], i1t[PRE ? UB : 1];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         i0[u] = O0.t_col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
         i1[u] = O1.t_col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+        if constexpr (PRE) {
+          i0t[u] = O0.t_col[e0 > b0 ? min(b0 + UB + u, e0 - 1) : 0];
+          i1t[u] = O1.t_col[e1 > b1 ? min(b1 + UB + u, e1 - 1) : 0];
+        }
       }
       float d0[UB], d1[UB];
       Acc<VEC> v0[UB], v1[UB];
@@ -573,8 +605,35 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
 #pragma unroll
       for (int u = 0; u < UB; ++u)
         if (b1 + u < e1) a1[0].add_mul(v1[u], d1[u]);
-      if (e0 - b0 > UB) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + UB, e0, c0, O0.F);
-      if (e1 - b1 > UB) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + UB, e1, c0, O1.F);
+      int done = UB;
+      if constexpr (PRE) {
+        if (e0 - b0 > UB || e1 - b1 > UB) {  // second batch through the same registers (ids already here)
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            d0[u] = dg ? O0.degf[i0t[u]] : 1.f;
+            d1[u] = dg ? O1.degf[i1t[u]] : 1.f;
+            v0[u].load(O0.g + (int64_t)i0t[u] * O0.ldg + cc0);
+            v1[u].load(O1.g + (int64_t)i1t[u] * O1.ldg + cc1);
+          }
+          if (a.mean && !dg) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              const int g0 = O0.rowptr[i0t[u] + 1] - O0.rowptr[i0t[u]], g1 = O1.rowptr[i1t[u] + 1] - O1.rowptr[i1t[u]];
+              d0[u] = 1.f / (float)(g0 > 1 ? g0 : 1);
+              d1[u] = 1.f / (float)(g1 > 1 ? g1 : 1);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (b0 + UB + u < e0) a0[0].add_mul(v0[u], d0[u]);
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (b1 + UB + u < e1) a1[0].add_mul(v1[u], d1[u]);
+        }
+        done = 2 * UB;
+      }
+      if (e0 - b0 > done) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + done, e0, c0, O0.F);
+      if (e1 - b1 > done) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + done, e1, c0, O1.F);
       if (c0 < O0.F) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
       if (has2 && c0 < O1.F) a1[0].store(S.dz + (int64_t)row * S.lddz + O1.coff + c0);
     }
@@ -653,11 +712,17 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
       const TAggOut& O1 = S.out[has2 ? oi + 1 : oi];
       const int b0 = rb[oi], e0 = re[oi];
       const int b1 = has2 ? rb[oi + 1] : b0, e1 = has2 ? re[oi + 1] : b0;
-      int i0[UB], i1[UB];
+      // GS <= 16: the ids of out-edges 8..15 travel with those of 0..7 (see agg_row): one round trip less for rows of 9..16 edges
+      constexpr bool PRE = GS <= 16;
+      int i0[UB], i1[UB], i0t[PRE ? UB : 1], i1t[PRE ? UB : 1];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         i0[u] = O0.t_col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
         i1[u] = O1.t_col[e1 > b1 ? min(b1 + u, e1 - 1) : 0];
+        if constexpr (PRE) {
+          i0t[u] = O0.t_col[e0 > b0 ? min(b0 + UB + u, e0 - 1) : 0];
+          i1t[u] = O1.t_col[e1 > b1 ? min(b1 + UB + u, e1 - 1) : 0];
+        }
       }
       float d0[UB], d1[UB];
       Acc<VEC> v0[UB], v1[UB];
@@ -687,8 +752,35 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
 #pragma unroll
       for (int u = 0; u < UB; ++u)
         if (b1 + u < e1) a1[0].add_mul(v1[u], d1[u]);
-      if (e0 - b0 > UB) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + UB, e0, c0, O0.F);
-      if (e1 - b1 > UB) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + UB, e1, c0, O1.F);
+      int done = UB;
+      if constexpr (PRE) {
+        if (e0 - b0 > UB || e1 - b1 > UB) {  // second batch through the same registers (ids already here)
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            d0[u] = dg ? O0.degf[i0t[u]] : 1.f;
+            d1[u] = dg ? O1.degf[i1t[u]] : 1.f;
+            v0[u].load(O0.g + (int64_t)i0t[u] * O0.ldg + cc0);
+            v1[u].load(O1.g + (int64_t)i1t[u] * O1.ldg + cc1);
+          }
+          if (a.mean && !dg) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              const int g0 = O0.rowptr[i0t[u] + 1] - O0.rowptr[i0t[u]], g1 = O1.rowptr[i1t[u] + 1] - O1.rowptr[i1t[u]];
+              d0[u] = 1.f / (float)(g0 > 1 ? g0 : 1);
+              d1[u] = 1.f / (float)(g1 > 1 ? g1 : 1);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (b0 + UB + u < e0) a0[0].add_mul(v0[u], d0[u]);
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (b1 + UB + u < e1) a1[0].add_mul(v1[u], d1[u]);
+        }
+        done = 2 * UB;
+      }
+      if (e0 - b0 > done) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + done, e0, c0, O0.F);
+      if (e1 - b1 > done) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + done, e1, c0, O1.F);
       if (c0 < O0.F) {
         if (live) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
 #pragma unroll
