@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
         if (dir == 0) {
           J.eid[pos] = mine;
           J.col[pos] = other;  // source endpoint
-          J.pos_of_eid[mine] = pos;
+          if (pb.need_tpos) J.pos_of_eid[mine] = pos;  // 4-byte scatter over all edges: only the link pass (t_pos) reads it
         } else {
           J.t_eid[pos] = mine;
           J.t_col[pos] = other;  // destination endpoint
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
         if (dir == 0) {
           J.eid[pos] = mine;
           J.col[pos] = tmpc[b + c];
-          J.pos_of_eid[mine] = pos;
+          if (pb.need_tpos) J.pos_of_eid[mine] = pos;  // 4-byte scatter over all edges: only the link pass (t_pos) reads it
         } else {
           J.t_eid[pos] = mine;
           J.t_col[pos] = tmpc[b + c];
