@@ -314,9 +314,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
 // idle and measured slower).
 // Measured on top of this kernel and rejected (config 5, 28.7 ms/step): a bf16 image of the stacked weights as B operand (half
 // the bytes, the same number of requests per stage: forward 5.14 -> 5.19 ms, backward 8.25 -> 8.99 ms) and two stages of register
-// prefetch instead of one (256 VGPRs + scratch spills: forward 5.50 ms, backward 13.5 ms).  Neither bytes nor requests in flight
-// per CU is what holds the 256x256 tile at ~47 us; the next candidate is a B-stationary persistent form (the 256 x 256 bf16
-// weight tile fits LDS) with LDS-DMA staging of A.
+// prefetch instead of one (256 VGPRs + scratch spills: forward 5.50 ms, backward 13.5 ms).  The cause was elsewhere (the ISA: every load
+// of a stage was waited for before the next, see bf_load_fast / the epilogue).  With that fixed the kernel moves ~7.5 TB/s through
+// L2; two stages of prefetch were measured again on the clean loader (no spills for the plain products) and are still slower
+// (forward 2.72 -> 2.87 ms, backward 3.75 -> 4.04 ms): the bound is L2 -> CU bytes now.  AGPRs are no extra budget here: 8
+// waves per CU = 2 per SIMD = 256 registers per wave, VGPRs and AGPRs together.  Next candidate: a B-stationary persistent
+// form (the 256 x 256 bf16 weight tile fits LDS).
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
   // 256x256 tiles when every problem is a product with at least 4096 x 192 outputs (plain) / 192 x 192 outputs over >= 2^17
