@@ -317,7 +317,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
 // prefetch instead of one (256 VGPRs + scratch spills: forward 5.50 ms, backward 13.5 ms).  The cause was elsewhere (the ISA: every load
 // of a stage was waited for before the next, see bf_load_fast / the epilogue).  With that fixed the kernel moves ~7.5 TB/s through
 // L2; two stages of prefetch were measured again on the clean loader (no spills for the plain products) and are still slower
-// (forward 2.72 -> 2.87 ms, backward 3.75 -> 4.04 ms): the bound is L2 -> CU bytes now.  AGPRs are no extra budget here: 8
+// (forward 2.72 -> 2.87 ms, backward 3.75 -> 4.04 ms), and so is the bf16 weight image (2.75 / 4.03 ms): neither bytes nor
+// requests explain the ~26 us per tile that remain (MFMA floor 3.4 us); LDS traffic / barriers are the untested suspects.  AGPRs are no extra budget here: 8
 // waves per CU = 2 per SIMD = 256 registers per wave, VGPRs and AGPRs together.  Next candidate: a B-stationary persistent
 // form (the 256 x 256 bf16 weight tile fits LDS).
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
