@@ -46,11 +46,25 @@ struct Acc<1> {
   __device__ __forceinline__ float& at(int) { return v; }
 };
 
+// Projected rows stored as bf16 (bf16 compute mode at 10^6 rows: halves the projection's write and the gather's read traffic):
+// ZB = true reads 4 bf16 (8 bytes) at ELEMENT index `idx` of the buffer and widens them; the buffer is typed float* like the
+// fp32 one, offsets and leading dimensions count elements either way.
+template <bool ZB>
+__device__ __forceinline__ void load_z(Acc<4>& a, const float* base, int64_t idx) {
+  if constexpr (ZB) {
+    const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    a.v = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u), __uint_as_float(b.y << 16),
+                      __uint_as_float(b.y & 0xffff0000u));
+  } else {
+    a.load(base + idx);
+  }
+}
+
 // sum_{k in [b,e)} x[col[k]][c .. c+VEC)   in edge order; NV column chunks per lane (stride GS*VEC).
 // Neighbours are processed in batches of UB = 8 (4 for wide rows) with NO tail loop: ids beyond the row are clamped to the
 // last valid entry (same address => cache hit) and masked at the add.  A row of degree <= 8 therefore costs three
 // dependent memory round trips (extent, ids, rows) instead of one per tail neighbour.
-template <int GS, int NV, int VEC>
+template <int GS, int NV, int VEC, bool ZB = false>
 __device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __restrict__ x, int ld, const int* __restrict__ col,
                                            int b, int e, int c0, int F) {
   constexpr int UB = (NV == 1) ? 8 : 4;
@@ -64,7 +78,10 @@ __device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __r
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int c = c0 + q * GS * VEC;
-        if (c < F) v[u][q].load(x + (int64_t)j[u] * ld + c);
+        if (c < F) {
+          if constexpr (ZB && VEC == 4) load_z<true>(v[u][q], x, (int64_t)j[u] * ld + c);
+          else v[u][q].load(x + (int64_t)j[u] * ld + c);
+        }
       }
     const int cnt = e - k;
 #pragma unroll
@@ -83,7 +100,7 @@ __device__ __forceinline__ void gather_sum(Acc<VEC> (&acc)[NV], const float* __r
 // `rdeg` (the reciprocal per destination, written by the plan) removes the two dependent rowptr loads per edge AND the
 // per-edge fp32 divisions (4 per lane and edge: ~1 ms of the config-5 transposed aggregation); without it (unit entry
 // point) the reciprocal is derived from rowptr.  Same clamped batches as gather_sum.
-template <int GS, int NV, int VEC>
+template <int GS, int NV, int VEC, bool GB = false>
 __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* __restrict__ g, int ld, const int* __restrict__ tcol,
                                              const int* __restrict__ rowptr, const float* __restrict__ rdeg, int mean, int b, int e,
                                              int c0, int F) {
@@ -111,7 +128,10 @@ __device__ __forceinline__ void gather_sum_w(Acc<VEC> (&acc)[NV], const float* _
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int c = c0 + q * GS * VEC;
-        if (c < F) v[u][q].load(g + (int64_t)i[u] * ld + c);
+        if (c < F) {
+          if constexpr (GB && VEC == 4) load_z<true>(v[u][q], g, (int64_t)i[u] * ld + c);
+          else v[u][q].load(g + (int64_t)i[u] * ld + c);
+        }
       }
     const int cnt = e - k;
 #pragma unroll
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
 
 // ----- fused SAGE layer aggregation -----------------------------------------------------------------
 // out[t][i] = dropout(act( zroot[i] + bias + sum_e mean_{k in N_e(i)} z_e[col_k] ))   (one row group, result also in `tot`)
-template <int GS, int NV>
+template <int GS, int NV, bool ZB = false>
 __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int c0, Acc<4> (&tot)[NV]) {
   constexpr int VEC = 4;
   // dropout coordinates incl. the device step counter: read now, not behind the gathers (one dependent round trip less)
@@ -181,7 +201,7 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
     const int c = c0 + q * GS * VEC;
     tot[q].zero();
     if (c < D.F) {
-      if (D.zroot) tot[q].load(D.zroot + (int64_t)row * D.ldzr + D.roff + c);
+      if (D.zroot) load_z<ZB>(tot[q], D.zroot, (int64_t)row * D.ldzr + D.roff + c);
       if (D.bias) { Acc<VEC> b; b.load(D.bias + c); tot[q].add(b); }
     }
   }
@@ -219,20 +239,21 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
       a1[0].zero();
       if (e0 > b0) {  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < UB; ++u) v[u].load(I0.z + I0.coff + (int64_t)j0[u] * I0.ldz + cc);
+        for (int u = 0; u < UB; ++u) load_z<ZB>(v[u], I0.z, I0.coff + (int64_t)j0[u] * I0.ldz + cc);
 #pragma unroll
         for (int u = 0; u < UB; ++u)
           if (b0 + u < e0) a0[0].add(v[u]);
       }
       if (e1 > b1) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) v[u].load(I1.z + I1.coff + (int64_t)j1[u] * I1.ldz + cc);
+        for (int u = 0; u < UB; ++u) load_z<ZB>(v[u], I1.z, I1.coff + (int64_t)j1[u] * I1.ldz + cc);
 #pragma unroll
         for (int u = 0; u < UB; ++u)
           if (b1 + u < e1) a1[0].add(v[u]);
       }
-      if (e0 - b0 > UB) gather_sum<GS, 1, VEC>(a0, I0.z + I0.coff, I0.ldz, I0.col, b0 + UB, e0, c0, D.F);
-      if (e1 - b1 > UB) gather_sum<GS, 1, VEC>(a1, I1.z + I1.coff, I1.ldz, I1.col, b1 + UB, e1, c0, D.F);
+      // (ZB: the column offset goes into the element index, the base pointer stays the buffer start)
+      if (e0 - b0 > UB) gather_sum<GS, 1, VEC, ZB>(a0, ZB ? I0.z : I0.z + I0.coff, I0.ldz, I0.col, b0 + UB, e0, ZB ? c0 + I0.coff : c0, ZB ? D.F + I0.coff : D.F);
+      if (e1 - b1 > UB) gather_sum<GS, 1, VEC, ZB>(a1, ZB ? I1.z : I1.z + I1.coff, I1.ldz, I1.col, b1 + UB, e1, ZB ? c0 + I1.coff : c0, ZB ? D.F + I1.coff : D.F);
       if (cin) {
         if (e0 > b0) tot[0].add_div(a0[0], mean ? (float)(e0 - b0) : 1.f);
         if (e1 > b1) tot[0].add_div(a1[0], mean ? (float)(e1 - b1) : 1.f);
@@ -388,7 +409,7 @@ __device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, in
   }
 }
 
-template <int GS, int NV>
+template <int GS, int NV, bool ZB = false>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   int ti = 0;
   while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   // the label is requested before the aggregation (it depends on nothing): one round trip less behind the last gather
   int64_t y = 0;
   if (NV == 1 && D.ce_labels) y = D.ce_labels[row];
-  agg_row<GS, NV>(D, a.mean, row, c0, tot);
+  agg_row<GS, NV, ZB>(D, a.mean, row, c0, tot);
   if constexpr (NV == 1) {
     if (D.ce_labels) ce_rowgroup<GS>(D, a.state, row, c0, tot[0], y);
   }
@@ -530,7 +551,8 @@ __device__ __forceinline__ void finalize_loss(const float* __restrict__ row_lv, 
 }
 
 // dz[s][j, seg_e] = sum_{k in out_e(j)} g'[dst_k] / deg(dst_k);   dz[s][j, root] = g'[s][j]
-template <int GS, int NV>
+// GB: the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements (bf16 compute mode at 10^6 rows, see load_z)
+template <int GS, int NV, bool GB = false>
 __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   constexpr int VEC = 4;
   if ((int)blockIdx.x == a.total_blocks) {  // the extra block (only launched when fin_row_lv is set)
@@ -585,8 +607,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       for (int u = 0; u < UB; ++u) {
         d0[u] = dg ? O0.degf[i0[u]] : 1.f;
         d1[u] = dg ? O1.degf[i1[u]] : 1.f;
-        v0[u].load(O0.g + (int64_t)i0[u] * O0.ldg + cc0);
-        v1[u].load(O1.g + (int64_t)i1[u] * O1.ldg + cc1);
+        load_z<GB>(v0[u], O0.g, (int64_t)i0[u] * O0.ldg + cc0);
+        load_z<GB>(v1[u], O1.g, (int64_t)i1[u] * O1.ldg + cc1);
       }
       if (a.mean && !dg) {
 #pragma unroll
@@ -612,8 +634,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
           for (int u = 0; u < UB; ++u) {
             d0[u] = dg ? O0.degf[i0t[u]] : 1.f;
             d1[u] = dg ? O1.degf[i1t[u]] : 1.f;
-            v0[u].load(O0.g + (int64_t)i0t[u] * O0.ldg + cc0);
-            v1[u].load(O1.g + (int64_t)i1t[u] * O1.ldg + cc1);
+            load_z<GB>(v0[u], O0.g, (int64_t)i0t[u] * O0.ldg + cc0);
+            load_z<GB>(v1[u], O1.g, (int64_t)i1t[u] * O1.ldg + cc1);
           }
           if (a.mean && !dg) {
 #pragma unroll
@@ -632,8 +654,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
         }
         done = 2 * UB;
       }
-      if (e0 - b0 > done) gather_sum_w<GS, 1, VEC>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + done, e0, c0, O0.F);
-      if (e1 - b1 > done) gather_sum_w<GS, 1, VEC>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + done, e1, c0, O1.F);
+      if (e0 - b0 > done) gather_sum_w<GS, 1, VEC, GB>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + done, e0, c0, O0.F);
+      if (e1 - b1 > done) gather_sum_w<GS, 1, VEC, GB>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + done, e1, c0, O1.F);
       if (c0 < O0.F) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
       if (has2 && c0 < O1.F) a1[0].store(S.dz + (int64_t)row * S.lddz + O1.coff + c0);
     }
@@ -645,7 +667,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
     Acc<VEC> acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q].zero();
-    gather_sum_w<GS, NV, VEC>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, rb[oi], re[oi], c0, O.F);
+    gather_sum_w<GS, NV, VEC, GB>(acc, O.g, O.ldg, O.t_col, O.rowptr, O.degf, a.mean, rb[oi], re[oi], c0, O.F);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c = c0 + q * GS * VEC;
@@ -659,7 +681,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       const int c = c0 + q * GS * VEC;
       if (c < S.Froot) {
         Acc<VEC> v;
-        v.load(S.groot + (int64_t)row * S.ldgr + c);
+        load_z<GB>(v, S.groot, (int64_t)row * S.ldgr + c);
         v.store(S.dz + (int64_t)row * S.lddz + S.roff + c);
       }
     }
@@ -909,6 +931,12 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
   }
   a.total_blocks = blocks;
   if (blocks == 0) return HMP_OK;
+  if (a.zb16) {  // bf16 projected rows: only the one-wavefront-per-row shape reads them
+    HMP_CHECK_ARG(gs == 64 && nv == 1, "agg_fwd: bf16 projected rows need row widths in (128, 256], got %d", Fmax);
+    hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true>), dim3(blocks), dim3(256), 0, st, a);
+    HMP_LAUNCH_CHECK();
+    return HMP_OK;
+  }
 #define LAUNCH_FWD(GS_, NV_) hipLaunchKernelGGL((agg_fwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_FWD)
 #undef LAUNCH_FWD
@@ -967,6 +995,12 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
   a.total_blocks = blocks;
   if (blocks == 0 && !a.fin_row_lv) return HMP_OK;
   const int grid = blocks + (a.fin_row_lv ? 1 : 0);
+  if (a.gb16) {  // bf16 gradient rows: only the one-wavefront-per-row shape reads them
+    HMP_CHECK_ARG(gs == 64 && nv == 1, "agg_bwd: bf16 gradient rows need row widths in (128, 256], got %d", Fmax);
+    hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true>), dim3(grid), dim3(256), 0, st, a);
+    HMP_LAUNCH_CHECK();
+    return HMP_OK;
+  }
 #define LAUNCH_BWD(GS_, NV_) hipLaunchKernelGGL((agg_bwd_kernel<GS_, NV_>), dim3(grid), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_BWD)
 #undef LAUNCH_BWD

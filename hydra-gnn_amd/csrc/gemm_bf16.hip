@@ -267,6 +267,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   const int Mrows = P.M, Ncols = P.N, ldc = P.ldc, ldh = P.ldh, act = P.act;
   const bool amask = P.epi == EPI_ACTMASK;
   const bool dropon = P.drop_on != 0;
+  const bool c16 = P.c_bf16 != 0;
   const float dscale = dropon ? P.drop.scale : 1.f;
   const float* Hp = P.H;
 #pragma unroll
@@ -285,15 +286,29 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
           hv[r] = Hp[(int64_t)(row < Mrows ? row : Mrows - 1) * ldh + colc];
         }
       }
+      float vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
         float v = acc[i][j][r];
         if (amask) {
           const bool keep = !dropon || (__float_as_uint(hv[r]) != 0x80000000u);  // dropped elements were stored as -0.0f
           v *= bf_act_mask(hv[r], act, keep, dscale);
         }
-        if (cok && row < Mrows) C[(int64_t)row * ldc + col] = v;
+        vv[r] = v;
+      }
+      if (c16) {  // block-uniform: bf16 projected rows (ldc counts elements)
+        __bf16* C16 = reinterpret_cast<__bf16*>(C);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (cok && row < Mrows) C16[(int64_t)row * ldc + col] = (__bf16)vv[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (cok && row < Mrows) C[(int64_t)row * ldc + col] = vv[r];
+        }
       }
     }
   if (ONES && ones_here && (lane & 31) == 0) {  // column 0 of the ones product -> C[:, n_real]

@@ -14,6 +14,7 @@ struct GemmProblem {
   const float* B;
   float* C;
   const float* H;        // EPI_ACTMASK: activations whose derivative masks C (same shape as C)
+  int c_bf16;            // gemm_bf16_kernel: C holds bf16 elements (ldc counts elements)
   int64_t slab_stride;   // split-K: slab z is written at C + z*slab_stride
   int M, N, K;
   int lda, ldb, ldc, ldh;
@@ -169,6 +170,7 @@ struct AggArgs {
   int total_blocks;
   int mean;  // divide every gather by max(deg,1)
   int xcd;   // large launches: consecutive row ranges stay on one XCD (block counts padded to 8 per entry), see agg_fwd_launch
+  int zb16;  // the projected rows (AggIn::z, AggDst::zroot) hold bf16 elements (bf16 compute mode, 256-wide rows)
   NetState* state;  // status bits (fused cross entropy: label out of range)
   AggDst d[HMP_MAX_NODE_TYPES];
 };
@@ -205,6 +207,7 @@ struct TAggArgs {
   int total_blocks;
   int mean;
   int xcd;  // as AggArgs::xcd
+  int gb16; // the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements
   // one extra block sums the per-row {loss, valid} pairs of the loss in fixed order -> fin_out2 / fin_state (null: off)
   const float* fin_row_lv;
   int fin_rows;

@@ -727,16 +727,20 @@ inline bool is_input(const hmp_net* n, int l, int t) { return l == 0 || (l == 1 
 const float* h_ptr(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.d_x[t] : n->H[l][t]; }
 int h_ld(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.ldx[t] : n->ld[l][t]; }
 
-// launches a list of GEMM problems in groups of GEMM_MAX_PROB; ksplit_out receives the split of each problem
-int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out, bool allow_bf16 = false) {
-  // bf16 compute mode: only the throughput-bound regime (>= 1024 64x64 tiles in the call) leaves the exact fp32 kernel
+// bf16 compute mode: only the throughput-bound regime (>= 1024 64x64 tiles in the call) leaves the exact fp32 kernel
+bool gemm_takes_bf16(const std::vector<GemmProblem>& ps, bool allow_bf16) {
   int64_t tiles64 = 0;
   double work = 0.0;
   for (const GemmProblem& p : ps) {
     tiles64 += (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
     work += (double)p.M * p.N * p.K;
   }
-  const bool bf16 = allow_bf16 && (tiles64 >= 1024 || work >= 1e9);
+  return allow_bf16 && (tiles64 >= 1024 || work >= 1e9);
+}
+
+// launches a list of GEMM problems in groups of GEMM_MAX_PROB; ksplit_out receives the split of each problem
+int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out, bool allow_bf16 = false) {
+  const bool bf16 = gemm_takes_bf16(ps, allow_bf16);
   for (size_t base = 0; base < ps.size(); base += GEMM_MAX_PROB) {
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
@@ -858,6 +862,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
     st = (l == 0) ? side : main_st;
+    bool z16 = false;  // this layer's projected rows are stored as bf16 (decided with the projection, read by the aggregation)
     if (l == 0 && front) {
       // projection, plan and pack already ran in the front kernel
     } else if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
@@ -874,6 +879,24 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         p.n_real = p.N;
         p.epi = EPI_NONE;
         ps.push_back(p);
+      }
+      // bf16 compute mode, 10^6-row regime: the projected rows are only ever gathered by this layer's aggregation, so they are
+      // stored as bf16 (half the projection's write and half the gather's read traffic) -- when the bf16 GEMM runs AND the
+      // aggregation takes its one-wavefront-per-row shape (every output width in (128, 256]), the one that reads bf16 rows
+      if (Y.kind != HMP_CONV_GAT && !n->fuse_now && gemm_takes_bf16(ps, n->compute_bf16 != 0)) {
+        int fmin = 1 << 30, fmax = 0;
+        for (int t = 0; t < n->T; ++t) {
+          if (Y.roff[t] < 0 || b->n_nodes[t] == 0) continue;
+          const int f = fpad(Ls.out_dim[t]);
+          fmin = f < fmin ? f : fmin;
+          fmax = f > fmax ? f : fmax;
+        }
+        z16 = fmax <= 256 && fmin > 128;
+        for (GemmProblem& p : ps) z16 = z16 && (p.ldc & 3) == 0;
+        const char* zv = getenv("HMP_Z16");  // 0: keep fp32 projected rows (tests)
+        if (zv && zv[0] == '0') z16 = false;
+        if (z16)
+          for (GemmProblem& p : ps) p.c_bf16 = 1;
       }
       HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
     }
@@ -948,6 +971,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         HMP_TRY(agg_proj_fwd_launch(a, st));
         z_done = true;
       } else {
+        a.zb16 = z16 ? 1 : 0;
         HMP_TRY(agg_fwd_launch(a, st));
       }
     }
@@ -994,6 +1018,8 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   std::vector<GemmProblem> wps;  // weight-gradient problems of all layers (merged mode)
   std::vector<int> wids;
   bool fin_early = false;
+  bool g16[HMP_MAX_LAYERS + 2];  // g16[l]: the input gradients G[l][*] were stored as bf16 by layer l's input-gradient GEMM
+  for (int i = 0; i < HMP_MAX_LAYERS + 2; ++i) g16[i] = false;
   for (int l = n->L - 1; l >= 0; --l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
@@ -1067,6 +1093,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         }
         HMP_TRY(agg_bwd_dx_launch(a, st));
       } else {
+        a.gb16 = g16[l + 1] ? 1 : 0;
         HMP_TRY(agg_bwd_launch(a, st));
       }
     }
@@ -1102,6 +1129,26 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           if (p.act == HMP_ACT_NONE && !p.drop_on) p.epi = EPI_NONE;
         }
         ps.push_back(p);
+      }
+      // bf16 compute mode, 10^6-row regime: G[l] is only ever gathered by layer l-1's transposed aggregation -> stored as bf16
+      // when this GEMM runs on the bf16 kernel and that aggregation takes its one-wavefront-per-row shape (see forward_impl)
+      if (l > 0 && !n->fuse_now && n->lay[l - 1].kind != HMP_CONV_GAT && gemm_takes_bf16(ps, n->compute_bf16 != 0)) {
+        const hmp_layer_spec& Lp = S.layers[l - 1];
+        int fmin = 1 << 30, fmax = 0;
+        for (int t = 0; t < n->T; ++t) {
+          if (n->lay[l - 1].roff[t] < 0 || b->n_nodes[t] == 0) continue;
+          const int f = fpad(Lp.out_dim[t]);
+          fmin = f < fmin ? f : fmin;
+          fmax = f > fmax ? f : fmax;
+        }
+        bool ok = fmax <= 256 && fmin > 128;
+        for (GemmProblem& p : ps) ok = ok && (p.ldc & 3) == 0;
+        const char* zv = getenv("HMP_Z16");  // 0: keep fp32 rows (tests)
+        if (zv && zv[0] == '0') ok = false;
+        if (ok) {
+          for (GemmProblem& p : ps) p.c_bf16 = 1;
+          g16[l] = true;
+        }
       }
       HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
     }
