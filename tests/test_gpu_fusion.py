@@ -255,6 +255,17 @@ def test_bf16_compute_mode_on_a_large_graph():
         err = float((gout[k] - gr).norm() / (gr.norm() + 1e-20))
         assert err < 8e-2, (k, err)
         assert float((gout[k] - gr).abs().max() / (gr.abs().max() + 1e-20)) < 0.25, k
+    # bf16 STORAGE of the projected rows / input gradients (on by default in this regime) against fp32 storage: same
+    # computation, one more rounding to bf16 per stored element
+    os.environ["HMP_Z16"] = "0"
+    try:
+        out32, g32 = fwd_bwd()
+    finally:
+        del os.environ["HMP_Z16"]
+    assert not torch.equal(out32, out)  # the bf16-storage path really ran by default
+    assert float((out32 - out).abs().max() / ref.abs().max()) < 2e-2
+    for k, gr in g32.items():
+        assert float((gout[k] - gr).norm() / (gr.norm() + 1e-20)) < 8e-2, k  # same budget as against fp32 compute (ReLU mask flips)
     small = workloads.config2_batch(2)
     _, net2 = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
     net2.eval()
