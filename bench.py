@@ -390,7 +390,11 @@ def main():
                                    "avg_launch_us": d["avg_us"]}
             out["roofline"]["note"] = ("launch/latency-bound regime: the whole step moves ~%.0f MB; every kernel is a chain of ~2 us "
                                        "dependent memory round trips (cold L2 after each kernel boundary), see DESIGN.md section 6"
-                                       % (sum(c["bytes"] for c in cost.values()) / 1e6)) if args.config != 5 else "bandwidth regime"
+                                       % (sum(c["bytes"] for c in cost.values()) / 1e6)) if args.config != 5 else (
+                "bandwidth regime" if args.precision != "bf16" else
+                "bandwidth regime; algorithmic bytes are counted at 4 bytes per element, but in this mode the projected rows Z and "
+                "the input gradients G are stored as bf16, so `achieved` overstates the bandwidth of the aggregation / projection "
+                "kernels by their Z / G terms (up to ~1.6x for the aggregation)")
             out["roofline_all"] = table
             # HBM traffic of the dominant family from the committed PMC passes of this same command (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_summary.py)
