@@ -60,6 +60,19 @@ __device__ __forceinline__ void load_z(Acc<4>& a, const float* base, int64_t idx
   }
 }
 
+// counterpart for buffers WRITTEN as bf16 (round to nearest even): 4 elements at element index `idx`
+template <bool ZB>
+__device__ __forceinline__ void store_z(const Acc<4>& a, float* base, int64_t idx) {
+  if constexpr (ZB) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    bf4 b;
+    b[0] = (__bf16)a.v.x; b[1] = (__bf16)a.v.y; b[2] = (__bf16)a.v.z; b[3] = (__bf16)a.v.w;
+    *reinterpret_cast<bf4*>(reinterpret_cast<uint16_t*>(base) + idx) = b;
+  } else {
+    a.store(base + idx);
+  }
+}
+
 // sum_{k in [b,e)} x[col[k]][c .. c+VEC)   in edge order; NV column chunks per lane (stride GS*VEC).
 // Neighbours are processed in batches of UB = 8 (4 for wide rows) with NO tail loop: ids beyond the row are clamped to the
 // last valid entry (same address => cache hit) and masked at the add.  A row of degree <= 8 therefore costs three
@@ -551,8 +564,9 @@ __device__ __forceinline__ void finalize_loss(const float* __restrict__ row_lv, 
 }
 
 // dz[s][j, seg_e] = sum_{k in out_e(j)} g'[dst_k] / deg(dst_k);   dz[s][j, root] = g'[s][j]
-// GB: the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements (bf16 compute mode at 10^6 rows, see load_z)
-template <int GS, int NV, bool GB = false>
+// GB: the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements (bf16 compute mode at 10^6 rows, see load_z);
+// DZB: so does the output dz (read back by the bf16 GEMMs as their A operand)
+template <int GS, int NV, bool GB = false, bool DZB = false>
 __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   constexpr int VEC = 4;
   if ((int)blockIdx.x == a.total_blocks) {  // the extra block (only launched when fin_row_lv is set)
@@ -656,8 +670,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       }
       if (e0 - b0 > done) gather_sum_w<GS, 1, VEC, GB>(a0, O0.g, O0.ldg, O0.t_col, O0.rowptr, O0.degf, a.mean, b0 + done, e0, c0, O0.F);
       if (e1 - b1 > done) gather_sum_w<GS, 1, VEC, GB>(a1, O1.g, O1.ldg, O1.t_col, O1.rowptr, O1.degf, a.mean, b1 + done, e1, c0, O1.F);
-      if (c0 < O0.F) a0[0].store(S.dz + (int64_t)row * S.lddz + O0.coff + c0);
-      if (has2 && c0 < O1.F) a1[0].store(S.dz + (int64_t)row * S.lddz + O1.coff + c0);
+      if (c0 < O0.F) store_z<DZB>(a0[0], S.dz, (int64_t)row * S.lddz + O0.coff + c0);
+      if (has2 && c0 < O1.F) store_z<DZB>(a1[0], S.dz, (int64_t)row * S.lddz + O1.coff + c0);
     }
   } else {
 #pragma unroll
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c = c0 + q * GS * VEC;
-      if (c < O.F) acc[q].store(S.dz + (int64_t)row * S.lddz + O.coff + c);
+      if (c < O.F) store_z<DZB>(acc[q], S.dz, (int64_t)row * S.lddz + O.coff + c);
     }
   }
   }
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
       if (c < S.Froot) {
         Acc<VEC> v;
         load_z<GB>(v, S.groot, (int64_t)row * S.ldgr + c);
-        v.store(S.dz + (int64_t)row * S.lddz + S.roff + c);
+        store_z<DZB>(v, S.dz, (int64_t)row * S.lddz + S.roff + c);
       }
     }
   }
@@ -997,10 +1011,12 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
   const int grid = blocks + (a.fin_row_lv ? 1 : 0);
   if (a.gb16) {  // bf16 gradient rows: only the one-wavefront-per-row shape reads them
     HMP_CHECK_ARG(gs == 64 && nv == 1, "agg_bwd: bf16 gradient rows need row widths in (128, 256], got %d", Fmax);
-    hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true>), dim3(grid), dim3(256), 0, st, a);
+    if (a.dzb16) hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true, false>), dim3(grid), dim3(256), 0, st, a);
     HMP_LAUNCH_CHECK();
     return HMP_OK;
   }
+  HMP_CHECK_ARG(!a.dzb16, "agg_bwd: a bf16 dz needs bf16 gradient rows (the one-wavefront-per-row kernel)");
 #define LAUNCH_BWD(GS_, NV_) hipLaunchKernelGGL((agg_bwd_kernel<GS_, NV_>), dim3(grid), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_BWD)
 #undef LAUNCH_BWD

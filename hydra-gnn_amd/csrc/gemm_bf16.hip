@@ -87,6 +87,77 @@ __device__ __forceinline__ void bf_mask(StageRegs<ROWS * BKB / 4 / NT>& t, int k
   }
 }
 
+// Operand that already exists as bf16 (dZ written by the transposed aggregation in bf16 compute mode): 8 bytes per slot, no
+// conversion.  Same slot mapping and the same issue-now / mask-later split as bf_load_fast; the 4 bf16 travel as raw bits in
+// v[i].x / .y.
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_load16(StageRegs<ROWS * BKB / 4 / NT>& t, const uint16_t* __restrict__ p, int ld, int kcontig, int r0, int R,
+                                          int k0, int kend) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < BNV; ++i) {
+    const int q = tid + i * NT;
+    uint2 bits;
+    if (kcontig) {
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
+      const int gr = r0 + r, gk = k0 + k4;
+      bits = *reinterpret_cast<const uint2*>(p + (int64_t)(gr < R ? gr : R - 1) * ld + (gk < kend ? gk : k0));
+    } else {
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      const int gk = k0 + k;
+      bits = *reinterpret_cast<const uint2*>(p + (int64_t)(gk < kend ? gk : k0) * ld + (r0 + r4));
+    }
+    t.v[i].x = __uint_as_float(bits.x);
+    t.v[i].y = __uint_as_float(bits.y);
+  }
+}
+
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_mask16(StageRegs<ROWS * BKB / 4 / NT>& t, int kcontig, int r0, int R, int k0, int kend) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < BNV; ++i) {
+    const int q = tid + i * NT;
+    uint32_t x = __float_as_uint(t.v[i].x), y = __float_as_uint(t.v[i].y);
+    if (kcontig) {
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
+      const int gk = k0 + k4;
+      const bool rl = r0 + r < R;
+      if (!(rl && gk + 0 < kend)) x &= 0xffff0000u;
+      if (!(rl && gk + 1 < kend)) x &= 0x0000ffffu;
+      if (!(rl && gk + 2 < kend)) y &= 0xffff0000u;
+      if (!(rl && gk + 3 < kend)) y &= 0x0000ffffu;
+    } else {
+      const int k = q / (ROWS / 4);
+      if (k0 + k >= kend) x = y = 0u;
+    }
+    t.v[i].x = __uint_as_float(x);
+    t.v[i].y = __uint_as_float(y);
+  }
+}
+
+template <int NT, int ROWS, int BKB>
+__device__ __forceinline__ void bf_store16(const StageRegs<ROWS * BKB / 4 / NT>& t, __bf16* __restrict__ s, int kcontig) {
+  constexpr int BNV = ROWS * BKB / 4 / NT;
+  constexpr int BPITCH = BKB + 8;
+  constexpr int RP = ROWS + 8;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < BNV; ++i) {
+    const int q = tid + i * NT;
+    const uint2 bits = make_uint2(__float_as_uint(t.v[i].x), __float_as_uint(t.v[i].y));
+    if (kcontig) {
+      const int r = q / (BKB / 4), k4 = (q % (BKB / 4)) * 4;
+      *reinterpret_cast<uint2*>(s + r * BPITCH + k4) = bits;
+    } else {
+      const int k = q / (ROWS / 4), r4 = (q % (ROWS / 4)) * 4;
+      *reinterpret_cast<uint2*>(s + k * RP + r4) = bits;
+    }
+  }
+}
+
 // edge loader: element by element with bounds (last column tile, ones column, unaligned operands)
 template <int NT, int ROWS, int BKB>
 __device__ __forceinline__ void bf_load_edge(StageRegs<ROWS * BKB / 4 / NT>& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R,
@@ -197,7 +268,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   // block-uniform loader choice
   const bool a_al = (P.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(P.A) & 15) == 0;
   const bool b_al = (P.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(P.B) & 15) == 0;
-  const bool a_fast = a_al && (a_kc || m0 + ROWS <= P.M);
+  const bool a_16 = P.a_bf16 != 0;  // host guarantees: 8-byte aligned rows, whole tiles (see GemmProblem::a_bf16)
+  const bool a_fast = !a_16 && a_al && (a_kc || m0 + ROWS <= P.M);
   const bool b_fast = b_al && (b_kc || n0 + ROWS <= P.n_real);
   // virtual ones column of B (bias gradient = column sums of A over k): instead of a whole extra column tile for ONE column
   // (a third of the config-5 weight-gradient work), the first column tile's wn == 0 waves run one more MFMA per row tile
@@ -225,16 +297,19 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
 
   StageRegs<ROWS * BKB / 4 / NT> ra, rb;
   auto load = [&](int k0) {
-    if (a_fast) bf_load_fast<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
+    if (a_16) bf_load16<NT, ROWS, BKB>(ra, reinterpret_cast<const uint16_t*>(P.A), P.lda, a_kc, m0, P.M, k0, kend);
+    else if (a_fast) bf_load_fast<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
     else bf_load_edge<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, P.M, 0, k0, kend);
     if (b_fast) bf_load_fast<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
     else bf_load_edge<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, P.n_real, P.aug_ones, k0, kend);
   };
   load(kbeg);
   for (int kt = kbeg; kt < kend; kt += BKB) {
-    if (a_fast) bf_mask<NT, ROWS, BKB>(ra, a_kc, m0, P.M, kt, kend);
+    if (a_16) bf_mask16<NT, ROWS, BKB>(ra, a_kc, m0, P.M, kt, kend);
+    else if (a_fast) bf_mask<NT, ROWS, BKB>(ra, a_kc, m0, P.M, kt, kend);
     if (b_fast) bf_mask<NT, ROWS, BKB>(rb, b_kc, n0, P.n_real, kt, kend);
-    bf_store<NT, ROWS, BKB>(ra, As, a_kc);
+    if (a_16) bf_store16<NT, ROWS, BKB>(ra, As, a_kc);
+    else bf_store<NT, ROWS, BKB>(ra, As, a_kc);
     bf_store<NT, ROWS, BKB>(rb, Bs, b_kc);
     __syncthreads();
     if (kt + BKB < kend) load(kt + BKB);

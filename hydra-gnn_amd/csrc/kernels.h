@@ -15,6 +15,7 @@ struct GemmProblem {
   float* C;
   const float* H;        // EPI_ACTMASK: activations whose derivative masks C (same shape as C)
   int c_bf16;            // gemm_bf16_kernel: C holds bf16 elements (ldc counts elements)
+  int a_bf16;            // gemm_bf16_kernel: A holds bf16 elements (lda counts elements); every tile must take the fast loader
   int64_t slab_stride;   // split-K: slab z is written at C + z*slab_stride
   int M, N, K;
   int lda, ldb, ldc, ldh;
@@ -208,6 +209,7 @@ struct TAggArgs {
   int mean;
   int xcd;  // as AggArgs::xcd
   int gb16; // the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements
+  int dzb16; // dz is written as bf16 (requires gb16)
   // one extra block sums the per-row {loss, valid} pairs of the loss in fixed order -> fin_out2 / fin_state (null: off)
   const float* fin_row_lv;
   int fin_rows;

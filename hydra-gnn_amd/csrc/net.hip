@@ -740,7 +740,12 @@ bool gemm_takes_bf16(const std::vector<GemmProblem>& ps, bool allow_bf16) {
 
 // launches a list of GEMM problems in groups of GEMM_MAX_PROB; ksplit_out receives the split of each problem
 int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out, bool allow_bf16 = false) {
-  const bool bf16 = gemm_takes_bf16(ps, allow_bf16);
+  bool bf16 = gemm_takes_bf16(ps, allow_bf16);
+  for (const GemmProblem& p : ps)
+    if (p.a_bf16 || p.c_bf16) {  // bf16-stored operands exist only for the bf16 kernel
+      HMP_CHECK_ARG(allow_bf16, "net: bf16-stored GEMM operand outside bf16 compute mode");
+      bf16 = true;
+    }
   for (size_t base = 0; base < ps.size(); base += GEMM_MAX_PROB) {
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
@@ -1020,6 +1025,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   bool fin_early = false;
   bool g16[HMP_MAX_LAYERS + 2];  // g16[l]: the input gradients G[l][*] were stored as bf16 by layer l's input-gradient GEMM
   for (int i = 0; i < HMP_MAX_LAYERS + 2; ++i) g16[i] = false;
+  bool dz16 = false;  // this layer's dZ is written as bf16 by the transposed aggregation (read by both backward GEMMs)
   for (int l = n->L - 1; l >= 0; --l) {
     const hmp_layer_spec& Ls = S.layers[l];
     LayerLayout& Y = n->lay[l];
@@ -1029,6 +1035,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       return n->G[l + 1][t];
     };
     bool dx_fused = false;
+    dz16 = false;
     if (Y.kind == HMP_CONV_GAT) {
       Scope sc(n, KC_GAT_BWD, st);
       GatDyn dyn = make_gat_dyn(n, b);
@@ -1094,6 +1101,16 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         HMP_TRY(agg_bwd_dx_launch(a, st));
       } else {
         a.gb16 = g16[l + 1] ? 1 : 0;
+        // dZ as bf16 too (it is only read back as the A operand of the two backward GEMMs): needs the bf16-reading kernel
+        // above and whole 256-row tiles of every dZ^T (the bf16 operand loader has no edge path)
+        dz16 = a.gb16 && n->compute_bf16 != 0;
+        for (int s = 0; s < n->T && dz16; ++s)
+          if (Y.ncols[s] > 0 && b->n_nodes[s] > 0 && (Y.ncols[s] % 256) != 0) dz16 = false;
+        {
+          const char* zv = getenv("HMP_Z16");
+          if (zv && zv[0] == '0') dz16 = false;
+        }
+        a.dzb16 = dz16 ? 1 : 0;
         HMP_TRY(agg_bwd_launch(a, st));
       }
     }
@@ -1116,6 +1133,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         GemmProblem p;
         memset(&p, 0, sizeof(p));
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 0;
+        p.a_bf16 = dz16 ? 1 : 0;
         p.B = n->d_packed + Y.wp_off[s]; p.ldb = Y.ldw[s]; p.trans_b = 0;
         p.C = dst; p.ldc = l > 0 ? n->ld[l][s] : b->ldx[s];
         p.M = b->n_nodes[s]; p.N = n->dim[l][s]; p.K = Y.ncols[s];
@@ -1167,6 +1185,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         GemmProblem p;
         memset(&p, 0, sizeof(p));
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 1;
+        p.a_bf16 = dz16 ? 1 : 0;
         p.B = h_ptr(n, l, s); p.ldb = h_ld(n, l, s); p.trans_b = 0;
         p.C = n->d_slabs + Y.slab_off[s]; p.ldc = Y.lddw[s];
         p.slab_stride = (int64_t)Y.ncols[s] * Y.lddw[s];
