@@ -108,7 +108,10 @@ int gemm_tn_direct_launch(TnBatch& tb, int max_slabs, int* ok, hipStream_t st) {
     TnProblem& P = tb.p[i];
     P.tiles_m = cdiv(P.M, 32);
     P.tiles_n = cdiv(P.N, 32);
-    int ks = cdiv(P.K, 2 * 4 * TN_MAXI * 2);  // at most two trips of 192 nodes per block
+    // at most two trips of 192 nodes per block -- four when the output alone already gives every CU several tiles (wide GAT
+    // layers: 595 tiles): half the slabs to write here and to sum in the gradient un-pack
+    const int trips = (P.tiles_m * P.tiles_n >= 512) ? 4 : 2;
+    int ks = cdiv(P.K, 2 * 4 * TN_MAXI * trips);
     if (ks < 1) ks = 1;
     if (ks > max_slabs) { *ok = 0; return HMP_OK; }
     // more slabs than necessary when the launch would otherwise be small: shorter MFMA chains, same round trip
