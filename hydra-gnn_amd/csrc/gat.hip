@@ -350,7 +350,7 @@ __device__ __forceinline__ void load_g(const GatDstS& D, const GatDyn& dyn, int 
 
 template <int HM, int GS>
 __global__ __launch_bounds__(256) void gat_bwd1_kernel(const GatLayerS* __restrict__ tab, const GatDyn dyn) {
-  constexpr int CAP = 16;  // edges per row whose sweep-0 scalars are parked in LDS (multiple of the batch size)
+  constexpr int CAP = 32;  // edges per row whose sweep-0 scalars are parked in LDS (multiple of the batch size; 16 KB at 8 rows x 4 heads: rooms with 17..32 objects no longer take the recompute path)
   __shared__ float cache[256 / GS][CAP][HM][4];
   int di = 0;
   while (di + 1 < tab->n_dst && (int)blockIdx.x >= dyn.block_start[di + 1]) ++di;
