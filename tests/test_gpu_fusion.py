@@ -310,3 +310,31 @@ def test_large_launch_xcd_row_mapping_is_bit_identical(hidden, monkeypatch):
     with torch.no_grad():
         ref = o64(b64)
     torch.testing.assert_close(out.cpu().double(), ref, atol=1e-4, rtol=1e-4)
+
+
+def test_bf16_mode_htree_many_edge_types():
+    """bf16 compute mode with bf16-stored Z / G / dZ on the H-tree program (up to 6 incoming edge types per node type, LeafPool
+    readout) at > 65 536 nodes: logits and gradients stay within bf16 rounding of the fp32 engine."""
+    dims = {"object": 306, "room": 6, "object-room": 6, "room-room": 6, "object_virtual": 306, "room_virtual": 6}
+    kw = dict(input_dim_dict=dims, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, disable_initialization=True,
+              dropout=0.0)
+    torch.manual_seed(3)
+    net = HeterogeneousNeuralTreeNetwork(**kw).to(DEV).eval()
+    g = workloads.htree_batch(96, seed=77).to(DEV)
+    assert sum(int(g[t].num_nodes) for t in g.node_types) > 65536
+    y = g["room_virtual"].y
+
+    def fwd_bwd():
+        for p in net.parameters():
+            p.grad = None
+        pred = net(g)
+        net.loss(pred, y, y != 25).backward()
+        return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    ref, gref = fwd_bwd()
+    net.native().set_compute("bf16")
+    out, gout = fwd_bwd()
+    assert not torch.equal(out, ref)
+    assert float((out - ref).abs().max() / ref.abs().max()) < 3e-2
+    for k, gr in gref.items():
+        assert float((gout[k] - gr).norm() / (gr.norm() + 1e-20)) < 0.1, k
