@@ -667,12 +667,16 @@ int dispatch(int H, int Cp, F&& f) {
     }                                                                                                        \
   } while (0)
 
-// all destination entries of a layer share H and Cp (the reference builds every edge type of a layer alike)
+// all destination entries of a layer share H (the reference builds every edge type of a layer alike); the channel count may
+// differ between destination types (last layer of the two-headed task: output_dim_dict): the kernels read Cp per destination
+// and mask their lanes with it, so the launch takes the row-group width of the widest one
 int layer_shape(const GatLayerS& h_tab, int& H, int& Cp) {
   HMP_CHECK_ARG(h_tab.n_dst > 0, "gat: empty layer table");
   H = h_tab.d[0].H; Cp = h_tab.d[0].Cp;
-  for (int i = 1; i < h_tab.n_dst; ++i)
-    HMP_CHECK_ARG(h_tab.d[i].H == H && h_tab.d[i].Cp == Cp, "gat: destination types of one layer must share heads / channels");
+  for (int i = 1; i < h_tab.n_dst; ++i) {
+    HMP_CHECK_ARG(h_tab.d[i].H == H, "gat: destination types of one layer must share the number of heads");
+    Cp = h_tab.d[i].Cp > Cp ? h_tab.d[i].Cp : Cp;
+  }
   return HMP_OK;
 }
 

@@ -155,6 +155,9 @@ int build_layout(hmp_net* n) {
   HMP_CHECK_ARG(n->L >= 1 && n->L <= HMP_MAX_LAYERS, "net: n_layers %d", n->L);
   HMP_CHECK_ARG(S.readout_type >= 0 && S.readout_type < n->T, "net: readout_type");
   HMP_CHECK_ARG(S.pool_edge_type >= -1 && S.pool_edge_type < n->ET, "net: pool_edge_type");
+  HMP_CHECK_ARG(S.aux_readout_type >= -1 && S.aux_readout_type < n->T && S.aux_readout_type != S.readout_type &&
+                    (S.aux_readout_type < 0 || S.pool_edge_type < 0),
+                "net: aux_readout_type (a second node type, not with a pooled output)");
   for (int e = 0; e < n->ET; ++e)
     HMP_CHECK_ARG(S.edge_src[e] >= 0 && S.edge_src[e] < n->T && S.edge_dst[e] >= 0 && S.edge_dst[e] < n->T, "net: edge type %d endpoints", e);
   for (int t = 0; t < n->T; ++t) {
@@ -268,7 +271,8 @@ int build_layout(hmp_net* n) {
     for (int i = 0; i < Y.n_live; ++i) {
       const hmp_conv_spec& C = S.layers[l].convs[Y.live[i]];
       if (l == n->L - 1)
-        HMP_CHECK_ARG(C.dst == S.readout_type, "net: last-layer conv %d is active but does not feed the readout type", Y.live[i]);
+        HMP_CHECK_ARG(C.dst == S.readout_type || C.dst == S.aux_readout_type,
+                      "net: last-layer conv %d is active but does not feed a readout type", Y.live[i]);
       else
         HMP_CHECK_ARG(n->lay[l + 1].ncols[C.dst] > 0, "net: layer %d conv %d is active but layer %d never reads its output", l, Y.live[i], l + 1);
     }
@@ -278,6 +282,7 @@ int build_layout(hmp_net* n) {
   n->out_dim = n->dim[n->L][S.readout_type];
   n->out_ld = fpad(n->out_dim);
   HMP_CHECK_ARG(n->out_dim > 0, "net: readout type has no output in the last layer");
+  HMP_CHECK_ARG(S.aux_readout_type < 0 || n->dim[n->L][S.aux_readout_type] > 0, "net: second readout type has no output in the last layer");
   return HMP_OK;
 }
 
@@ -555,7 +560,7 @@ int build_gat_tables(hmp_net* n) {
       D.drop_stream = (uint32_t)(l * HMP_MAX_NODE_TYPES + t);
       D.group_scale = Ls.group_mean ? 1.f / (float)Y.n_in[t] : 1.f;
       const bool top = (l == n->L - 1);
-      D.g = top ? nullptr : n->G[l + 1][t];
+      D.g = (top && t != S.aux_readout_type) ? nullptr : n->G[l + 1][t];  // second readout: its gradient is staged in G[L][aux]
       D.ldg = n->ld[l + 1][t];
       for (int i = 0; i < Y.n_live; ++i) {
         const int c = Y.live[i];
@@ -996,8 +1001,20 @@ const float* out_ptr(const hmp_net* n) {
 
 // ---- backward ------------------------------------------------------------------------------------------
 int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, const float* d_params, float* const* d_gx,
-                  hipStream_t st) {
+                  hipStream_t st, const float* d_gaux = nullptr, int ld_gaux = 0) {
   HMP_CHECK_ARG(n->have_fwd, "net: backward without a forward");
+  if (const int at = n->spec.aux_readout_type; at >= 0) {
+    // second readout: stage its gradient in G[L][aux] (zero where the caller passed none, and in the padding columns)
+    const int rows = n->batch.n_nodes[at], ld = n->ld[n->L][at], w = n->dim[n->L][at];
+    HMP_CHECK_ARG(!d_gaux || ld_gaux >= w, "net: second output gradient narrower than the output (%d < %d)", ld_gaux, w);
+    if (rows > 0) {
+      HMP_HIP(hipMemsetAsync(n->G[n->L][at], 0, (size_t)rows * ld * 4, st));
+      if (d_gaux)
+        HMP_HIP(hipMemcpy2DAsync(n->G[n->L][at], (size_t)ld * 4, d_gaux, (size_t)ld_gaux * 4, (size_t)w * 4, rows, hipMemcpyDeviceToDevice, st));
+    }
+  } else {
+    HMP_CHECK_ARG(!d_gaux, "net: a second output gradient for a net without aux_readout_type");
+  }
   HMP_CHECK_ARG((ld_gout & 3) == 0 && ld_gout >= n->out_ld && (reinterpret_cast<uintptr_t>(d_gout) & 15) == 0,
                 "net: output gradient must be 16-byte aligned with ld %% 4 == 0 and ld >= %d", n->out_ld);
   const hmp_net_spec& S = n->spec;
@@ -1369,9 +1386,34 @@ extern "C" int hmp_net_backward(hmp_net* n, const float* d_gout, int32_t ld_gout
   return backward_impl(n, d_gout, ld_gout, d_grads, d_params, d_gx, (hipStream_t)stream);
 }
 
+extern "C" int hmp_net_aux_output(hmp_net* n, const float** d_out, int32_t* ld_out, int32_t* n_rows) {
+  HMP_CHECK_ARG(n && d_out && ld_out && n_rows, "hmp_net_aux_output: null argument");
+  HMP_CHECK_ARG(n->spec.aux_readout_type >= 0 && n->have_fwd, "hmp_net_aux_output: needs aux_readout_type and a forward");
+  const int at = n->spec.aux_readout_type;
+  *d_out = n->H[n->L][at];
+  *ld_out = n->ld[n->L][at];
+  *n_rows = n->batch.n_nodes[at];
+  return HMP_OK;
+}
+
+extern "C" int hmp_net_backward2(hmp_net* n, const float* d_gout, int32_t ld_gout, const float* d_gout_aux, int32_t ld_aux,
+                                 const float* d_params, float* d_grads, float* const* d_gx, void* stream) {
+  HMP_CHECK_ARG(n && d_grads && d_params && (d_gout || d_gout_aux), "hmp_net_backward2: null argument");
+  HMP_CHECK_ARG(n->spec.aux_readout_type >= 0, "hmp_net_backward2: the net has one output (use hmp_net_backward)");
+  if (!d_gout) {  // no gradient for the first output: a zero block of its shape (G[L][readout] is free in the last layer)
+    HMP_CHECK_ARG(n->have_fwd, "net: backward without a forward");
+    const int rt = n->spec.readout_type, rows = n->batch.n_nodes[rt];
+    if (rows > 0) HMP_HIP(hipMemsetAsync(n->G[n->L][rt], 0, (size_t)rows * n->ld[n->L][rt] * 4, (hipStream_t)stream));
+    d_gout = n->G[n->L][rt];
+    ld_gout = n->ld[n->L][rt];
+  }
+  return backward_impl(n, d_gout, ld_gout, d_grads, d_params, d_gx, (hipStream_t)stream, d_gout_aux, ld_aux);
+}
+
 extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const float* d_params, float* d_grads,
                                     const hmp_train_args* args, void* stream) {
   HMP_CHECK_ARG(n && batch && d_params && d_grads && args, "hmp_net_step_fwd_bwd: null argument");
+  HMP_CHECK_ARG(n->spec.aux_readout_type < 0, "hmp_net_step_fwd_bwd: the fused step computes one cross entropy (single-output nets)");
   HMP_CHECK_ARG(batch->d_labels != nullptr, "hmp_net_step_fwd_bwd: labels required");
   hipStream_t st = (hipStream_t)stream;
   n->training = args->training; n->seed = args->seed; n->rng_step = 0; n->step_dev = true;
@@ -1392,6 +1434,7 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
 extern "C" int hmp_net_step_fused(hmp_net* n, const hmp_batch* batch, float* d_params, float* d_grads, float* d_m, float* d_v,
                                   const hmp_train_args* args, void* stream) {
   HMP_CHECK_ARG(n && batch && d_params && d_grads && d_m && d_v && args, "hmp_net_step_fused: null argument");
+  HMP_CHECK_ARG(n->spec.aux_readout_type < 0, "hmp_net_step_fused: the fused step computes one cross entropy (single-output nets)");
   AdamFuse& af = n->adam_fuse;
   af.on = n->fuse_mode == 0 ? 0 : 1;
   af.p = d_params; af.m = d_m; af.v = d_v;

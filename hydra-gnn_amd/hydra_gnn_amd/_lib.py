@@ -62,7 +62,7 @@ class NetSpec(C.Structure):
         ("n_node_types", C.c_int32), ("n_edge_types", C.c_int32), ("n_layers", C.c_int32),
         ("in_dim", C.c_int32 * MAX_NODE_TYPES),
         ("edge_src", C.c_int32 * MAX_EDGE_TYPES), ("edge_dst", C.c_int32 * MAX_EDGE_TYPES),
-        ("readout_type", C.c_int32), ("pool_edge_type", C.c_int32),
+        ("readout_type", C.c_int32), ("pool_edge_type", C.c_int32), ("aux_readout_type", C.c_int32),
         ("n_params", C.c_int64), ("n_active_params", C.c_int64),
         ("layers", LayerSpec * MAX_LAYERS),
     ]
@@ -121,6 +121,8 @@ SIGNATURES = {
     "hmp_net_bind_workspace": (C.c_int, [_VP, _VP, C.c_size_t, C.POINTER(_I32), C.POINTER(_I64)]),
     "hmp_net_forward": (C.c_int, [_VP, C.POINTER(Batch), _VP, _I32, _U64, _U32, C.POINTER(_VP), C.POINTER(_I32), _VP]),
     "hmp_net_backward": (C.c_int, [_VP, _VP, _I32, _VP, _VP, C.POINTER(_VP), _VP]),
+    "hmp_net_aux_output": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_I32)]),
+    "hmp_net_backward2": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP, C.POINTER(_VP), _VP]),
     "hmp_net_step_fwd_bwd": (C.c_int, [_VP, C.POINTER(Batch), _VP, _VP, C.POINTER(TrainArgs), _VP]),
     "hmp_net_step_adam": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(TrainArgs), _VP]),
     "hmp_net_step_fused": (C.c_int, [_VP, C.POINTER(Batch), _VP, _VP, _VP, _VP, C.POINTER(TrainArgs), _VP]),

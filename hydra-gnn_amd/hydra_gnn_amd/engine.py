@@ -64,12 +64,15 @@ class _BatchHolder:
 class NativeNet:
     def __init__(self, node_types: Sequence[str], in_dims: Dict[str, int], edge_types: Sequence[EdgeType],
                  layers: List[LayerDesc], readout: str, pool_edge_type: Optional[EdgeType] = None,
-                 count_types: Sequence[str] = ()):
+                 count_types: Sequence[str] = (), aux_readout: Optional[str] = None):
         self.node_types = list(node_types)
         self.edge_types = [tuple(e) for e in edge_types]
         self.in_dims = dict(in_dims)
         self.layers = layers
         self.readout = readout
+        # second output node type of the two-headed task (heterogeneous_network.py:123-135): forward returns (readout, aux)
+        self.aux_readout = aux_readout
+        assert aux_readout is None or (aux_readout != readout and pool_edge_type is None)
         self.pool_edge_type = tuple(pool_edge_type) if pool_edge_type is not None else None
         # node types without features whose node COUNT matters (virtual pool targets)
         self.count_types = list(count_types)
@@ -106,7 +109,7 @@ class NativeNet:
         """A conv is live iff its output can reach the readout (reference computes the others and
         throws them away: heterogeneous_network.py:121-122).  Dead convs keep their parameters
         (state_dict compatible) but receive no gradient, exactly like ``grad is None`` in torch."""
-        needed = {self.readout}
+        needed = {self.readout} | ({self.aux_readout} if self.aux_readout is not None else set())
         for layer in reversed(self.layers):
             nxt = set()
             for conv in layer.convs:
@@ -171,6 +174,7 @@ class NativeNet:
             sp.edge_src[i], sp.edge_dst[i] = nt[e[0]], nt[e[2]]
         sp.readout_type = nt[self.readout]
         sp.pool_edge_type = et[self.pool_edge_type] if self.pool_edge_type is not None else -1
+        sp.aux_readout_type = nt[self.aux_readout] if self.aux_readout is not None else -1
         sp.n_params, sp.n_active_params = self.n_params, self.n_active
         for l, layer in enumerate(self.layers):
             ls = sp.layers[l]
@@ -364,12 +368,25 @@ class NativeNet:
         _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), self._flat.data_ptr(), int(training), seed, rng_step,
                                              C.byref(out_p), C.byref(ld), _lib.stream_ptr()))
         self._fwd_token += 1
-        return self._ws_view(out_p.value, int(h.c.n_out), ld.value).clone()
+        out = self._ws_view(out_p.value, int(h.c.n_out), ld.value).clone()
+        if self.aux_readout is None:
+            return out
+        rows = C.c_int32()
+        _lib.check(self._lib.hmp_net_aux_output(self._handle, C.byref(out_p), C.byref(ld), C.byref(rows)))
+        return out, self._ws_view(out_p.value, rows.value, ld.value).clone()
 
-    def _backward_raw(self, gout: torch.Tensor) -> torch.Tensor:
-        grads = torch.zeros(self.n_params + 4, dtype=torch.float32, device=gout.device)
-        _lib.check(self._lib.hmp_net_backward(self._handle, gout.data_ptr(), gout.stride(0), self._flat.data_ptr(),
-                                              grads.data_ptr(), None, _lib.stream_ptr()))
+    def _backward_raw(self, gout: Optional[torch.Tensor], gaux: Optional[torch.Tensor] = None) -> torch.Tensor:
+        dev = (gout if gout is not None else gaux).device
+        grads = torch.zeros(self.n_params + 4, dtype=torch.float32, device=dev)
+        if self.aux_readout is None:
+            _lib.check(self._lib.hmp_net_backward(self._handle, gout.data_ptr(), gout.stride(0), self._flat.data_ptr(),
+                                                  grads.data_ptr(), None, _lib.stream_ptr()))
+        else:
+            _lib.check(self._lib.hmp_net_backward2(self._handle, gout.data_ptr() if gout is not None else None,
+                                                   gout.stride(0) if gout is not None else 0,
+                                                   gaux.data_ptr() if gaux is not None else None,
+                                                   gaux.stride(0) if gaux is not None else 0, self._flat.data_ptr(),
+                                                   grads.data_ptr(), None, _lib.stream_ptr()))
         return grads
 
     def read_state(self) -> Tuple[int, int]:
@@ -386,19 +403,24 @@ class _NetFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, gaux=None):
         net = ctx.net
         if ctx.token != net._fwd_token:
             raise _lib.HydraMPError(
                 "backward() after another forward() of the same model: the native executor keeps the "
                 "activations of the LAST forward only (one forward, then its backward)"
             )
-        gout = gout.contiguous()
-        if gout.stride(0) % 4 != 0 or gout.data_ptr() % 16 != 0:
-            padded = torch.zeros(gout.size(0), ((gout.size(1) + 3) // 4) * 4, dtype=gout.dtype, device=gout.device)
-            padded[:, : gout.size(1)] = gout
-            gout = padded
-        flat_g = net._backward_raw(gout)
+        if gout is not None:
+            gout = gout.contiguous()
+            if gout.stride(0) % 4 != 0 or gout.data_ptr() % 16 != 0:
+                padded = torch.zeros(gout.size(0), ((gout.size(1) + 3) // 4) * 4, dtype=gout.dtype, device=gout.device)
+                padded[:, : gout.size(1)] = gout
+                gout = padded
+        if gaux is not None:
+            gaux = gaux.contiguous()  # staged by the executor (any row pitch)
+        if gout is None and gaux is None:
+            return (None,) * (5 + len(net.params))
+        flat_g = net._backward_raw(gout, gaux)
         grads = []
         for p, live in zip(net.params, net.param_active):
             if not live:

@@ -37,6 +37,22 @@ class _NativeModule(nn.Module):
             self._rng_step += 1
         return net.forward(data, self.training, self._seed, self._rng_step)
 
+    def _drop_stream(self, l: int, node_type: str) -> int:
+        """RNG tensor id of the feature dropout after conv ``l`` on ``node_type`` (executor numbering: 8 * program layer + node
+        type index; a ``pre_mp`` layer in front shifts the program layers by one)"""
+        net = self.native()
+        return (l + len(net.layers) - self.num_layers) * 8 + net.node_types.index(node_type)
+
+    def _tail_act_drop(self, x, stream: int):
+        """activation + dropout on a final state of the two-headed task (reference heterogeneous_network.py:124-134): the native
+        program ends at the last conv, this is ``hmp_bias_act_drop_*`` on its output; keep-mask = tensor ``stream`` of this call's
+        RNG step (layer L-1 of the executor's numbering, which the executor itself never draws: its last layer has no dropout)"""
+        from .. import ops
+
+        gat = self.conv_block[:3] == "GAT"
+        return ops.bias_act_drop(x, None, relu=not gat, elu=gat, p=self.dropout if self.training else 0.0, seed=self._seed,
+                                 rng_step=self._rng_step, rng_stream=stream)
+
     def train_step(self, lr, weight_decay=0.0, **kw):
         """Fused native training step (fwd + masked CE + bwd [+ all-reduce] + Adam), see engine.TrainStep."""
         from ..engine import TrainStep
@@ -103,9 +119,7 @@ class HeterogeneousNetwork(_NativeModule):
             output_dim_dict = {"rooms": output_dim, "objects": output_dim}  # final objects states are ignored
         else:
             assert output_dim_dict is not None
-            raise NotImplementedError(
-                "classification_task='all' (output_dim_dict) belongs to the semi-supervised Stanford job, which is "
-                "outside the MI355X hot path (SURVEY.md section 2, rows 8 and 20)")
+            self.classification_task = "all"  # two outputs: the executor's second readout (hmp_net_aux_output / hmp_net_backward2)
         self.num_layers = num_layers if conv_block[:3] != "GAT" else len(GAT_heads)
         self.dropout = dropout
         self.input_dim_dict = dict(input_dim_dict)
@@ -126,8 +140,15 @@ class HeterogeneousNetwork(_NativeModule):
 
     def _build_native(self) -> NativeNet:
         node_types = ["objects", "rooms"]
-        return NativeNet(node_types, self.input_dim_dict, EDGE_TYPES, _hetero_layers(self, node_types), readout="rooms")
+        return NativeNet(node_types, self.input_dim_dict, EDGE_TYPES, _hetero_layers(self, node_types), readout="rooms",
+                         aux_readout="objects" if self.classification_task == "all" else None)
 
     def forward(self, data):
         out = self._run(data)
-        return out[:, : self.native().layers[-1].out_dims["rooms"]]
+        dims = self.native().layers[-1].out_dims
+        if self.classification_task == "room":
+            return out[:, : dims["rooms"]]
+        rooms, objects = out
+        last = self.num_layers - 1
+        return (self._tail_act_drop(rooms[:, : dims["rooms"]], self._drop_stream(last, "rooms")),
+                self._tail_act_drop(objects[:, : dims["objects"]], self._drop_stream(last, "objects")))

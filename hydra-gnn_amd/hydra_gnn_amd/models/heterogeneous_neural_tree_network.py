@@ -54,8 +54,7 @@ class HeterogeneousNeuralTreeNetwork(_NativeModule):
             output_dim_dict = {node_type: output_dim for node_type in HTREE_NODE_TYPES}
         else:
             assert output_dim_dict is not None
-            raise NotImplementedError(
-                "classification_task='all' belongs to the semi-supervised Stanford job (SURVEY.md section 2, row 8)")
+            self.classification_task = "all"  # two outputs (reference :186-205): second readout + LeafPool per head on the operators
         self.num_layers = num_layers if conv_block[:3] != "GAT" else len(GAT_heads)
         self.dropout = dropout
 
@@ -95,7 +94,13 @@ class HeterogeneousNeuralTreeNetwork(_NativeModule):
 
     def _build_native(self) -> NativeNet:
         layers = _hetero_layers(self, HTREE_NODE_TYPES)
+        two = self.classification_task == "all"
+        pool = dict(readout="room", aux_readout="object") if two else dict(readout="room", pool_edge_type=POOL_EDGE_TYPE)
+        pool_et = [] if two else [POOL_EDGE_TYPE]
         if self.pre_mp is None:
+            if two:
+                return NativeNet(list(HTREE_NODE_TYPES), {t: self.input_dim_dict[t] for t in HTREE_NODE_TYPES},
+                                 list(HTREE_EDGE_TYPES), layers, **pool)
             node_types = list(HTREE_NODE_TYPES) + ["room_virtual"]
             in_dims = {t: self.input_dim_dict[t] for t in HTREE_NODE_TYPES}
             return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + [POOL_EDGE_TYPE], layers,
@@ -109,9 +114,21 @@ class HeterogeneousNeuralTreeNetwork(_NativeModule):
         init = LayerDesc(convs, out_dims, ACT_NONE, 0.0, group_mean=(self.pre_mp.aggr == "mean"), passthrough=leaves)
         node_types = list(HTREE_NODE_TYPES) + ["room_virtual", "object_virtual"]
         in_dims = {t: self.input_dim_dict[t] for t in node_types}
-        return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + [POOL_EDGE_TYPE] + list(HTREE_INIT_EDGE_TYPES),
-                         [init] + layers, readout="room", pool_edge_type=POOL_EDGE_TYPE)
+        return NativeNet(node_types, in_dims, list(HTREE_EDGE_TYPES) + pool_et + list(HTREE_INIT_EDGE_TYPES),
+                         [init] + layers, **pool)
 
     def forward(self, data):
         out = self._run(data)
-        return out[:, : self.native().layers[-1].out_dims["room"]]
+        dims = self.native().layers[-1].out_dims
+        if self.classification_task == "room":
+            return out[:, : dims["room"]]
+        # reference :186-205: activation + dropout on the final states, then LeafPool per head, first N_virtual rows
+        from .. import ops
+
+        heads = []
+        for x, leaf, rel, virt in ((out[0], "room", "r_to_rv", "room_virtual"), (out[1], "object", "o_to_ov", "object_virtual")):
+            h = self._tail_act_drop(x[:, : dims[leaf]], self._drop_stream(self.num_layers - 1, leaf))
+            n_virtual = int(data[virt].num_nodes)
+            plan = ops.GraphPlan(data[leaf, rel, virt].edge_index, n_virtual, num_src=h.size(0))
+            heads.append(ops.segment_mean(h, plan))
+        return tuple(heads)

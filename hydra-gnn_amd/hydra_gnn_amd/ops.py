@@ -31,17 +31,20 @@ class GraphPlan:
     """CSR (by destination) + CSC lists of one square ``edge_index`` (``hmp_plan_build``), built once per batch and
     shared by every layer; ``dinv`` is GCN's ``deg^-1/2`` with the replaced self loops counted (``hmp_gcn_norm``)."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, num_src: Optional[int] = None):
+        """``num_src``: rows of the source side when the edge type is bipartite (LeafPool over ``room -> room_virtual``);
+        the GCN / GIN operators need the square form"""
         if not edge_index.is_cuda:
             raise _lib.HydraMPError("edge_index is on the CPU; hydra_gnn_amd has no CPU fallback")
         lib = _lib.require_device()
         ei = edge_index.to(torch.int64).contiguous()
         E, d, n = int(ei.size(1)), ei.device, int(num_nodes)
-        self.n, self.E, self.device = n, E, d
+        ns = n if num_src is None else int(num_src)
+        self.n, self.n_src, self.E, self.device = n, ns, E, d
         i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=d)
-        self._t = [i32(n + 1), i32(E), i32(E), i32(n + 1), i32(E), i32(E)]
-        self.plan = _lib.Plan(n, n, E, *[t.data_ptr() for t in self._t])
-        scratch = torch.empty(max(int(lib.hmp_plan_scratch_bytes(E, n, n)), 16), dtype=torch.uint8, device=d)
+        self._t = [i32(n + 1), i32(E), i32(E), i32(ns + 1), i32(E), i32(E)]
+        self.plan = _lib.Plan(ns, n, E, *[t.data_ptr() for t in self._t])
+        scratch = torch.empty(max(int(lib.hmp_plan_scratch_bytes(E, ns, n)), 16), dtype=torch.uint8, device=d)
         self.status = torch.zeros(1, dtype=torch.int32, device=d)
         with torch.cuda.device(d):
             _lib.check(lib.hmp_plan_build(ei.data_ptr() if E > 0 else None, self.plan, scratch.data_ptr(), self.status.data_ptr(),
@@ -107,8 +110,8 @@ class _WSum(torch.autograd.Function):
     def forward(ctx, z, plan: GraphPlan, gcn: bool, eps):
         _dev(z, "z")
         z = _rows(z)
-        if z.size(0) != plan.n:
-            raise _lib.HydraMPError(f"segment_wsum: {z.size(0)} rows for a plan over {plan.n} nodes")
+        if z.size(0) != plan.n or plan.n_src != plan.n:
+            raise _lib.HydraMPError(f"segment_wsum: {z.size(0)} rows for a plan over {plan.n_src} -> {plan.n} nodes (square plans only)")
         ctx.plan, ctx.gcn = plan, gcn
         ctx.save_for_backward(z, eps if eps is not None else z.new_empty(0))
         ctx.has_eps = eps is not None
@@ -214,8 +217,8 @@ class _SegmentMean(torch.autograd.Function):
     def forward(ctx, x, plan: GraphPlan):
         _dev(x, "x")
         x = _rows(x)
-        if x.size(0) != plan.n:
-            raise _lib.HydraMPError(f"segment_mean: {x.size(0)} rows for a plan over {plan.n} nodes")
+        if x.size(0) != plan.n_src:
+            raise _lib.HydraMPError(f"segment_mean: {x.size(0)} rows for a plan over {plan.n_src} source nodes")
         ctx.plan = plan
         out = torch.empty((plan.n, x.size(1)), dtype=torch.float32, device=x.device)
         if out.numel():
@@ -227,8 +230,10 @@ class _SegmentMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = _rows(g)
-        gx = torch.empty((ctx.plan.n, g.size(1)), dtype=torch.float32, device=g.device)
-        if gx.numel():
+        gx = torch.empty((ctx.plan.n_src, g.size(1)), dtype=torch.float32, device=g.device)
+        if gx.numel() and ctx.plan.n == 0:
+            gx.zero_()
+        elif gx.numel():
             with torch.cuda.device(g.device):
                 _lib.check(_lib.load().hmp_segment_mean_bwd(g.data_ptr(), g.stride(0), g.size(1), ctx.plan.plan, gx.data_ptr(),
                                                              gx.stride(0), _lib.stream_ptr()))

@@ -203,6 +203,9 @@ typedef struct hmp_net_spec {
   int32_t edge_src[HMP_MAX_EDGE_TYPES], edge_dst[HMP_MAX_EDGE_TYPES];
   int32_t readout_type;    /* node type whose final state is the output */
   int32_t pool_edge_type;  /* -1, or LeafPool edge type: output = segment mean over it, first n_out rows */
+  int32_t aux_readout_type; /* -1, or a SECOND node type whose final state is an output too: the two-headed task
+                             * (`return x_dict["rooms"], x_dict["objects"]`, heterogeneous_network.py:123-135); read with
+                             * hmp_net_aux_output, its gradient enters through hmp_net_backward2 */
   int64_t n_params;        /* total floats in the flat parameter buffer */
   int64_t n_active_params; /* parameters [0, n_active) receive gradients; the tail is dead weights */
   hmp_layer_spec layers[HMP_MAX_LAYERS];
@@ -242,6 +245,12 @@ int hmp_net_forward(hmp_net* net, const hmp_batch* batch, const float* d_params,
  * (overwritten, not accumulated).  d_gx[t] (may be NULL) receives d loss / d x[t], ld = ldx[t]. */
 int hmp_net_backward(hmp_net* net, const float* d_gout, int32_t ld_gout, const float* d_params, float* d_grads,
                      float* const* d_gx, void* stream);
+/* two-headed nets (spec.aux_readout_type >= 0): the final state of the second node type after the last forward
+ * ([*n_rows, *ld_out] inside the workspace), and the backward that takes a gradient for both outputs (either may be NULL = zero;
+ * d_gout_aux is [n_nodes[aux], ld_aux], any ld >= the type's output width). */
+int hmp_net_aux_output(hmp_net* net, const float** d_out, int32_t* ld_out, int32_t* n_rows);
+int hmp_net_backward2(hmp_net* net, const float* d_gout, int32_t ld_gout, const float* d_gout_aux, int32_t ld_aux,
+                      const float* d_params, float* d_grads, float* const* d_gx, void* stream);
 
 /* fused training step, phase A: plan + forward + masked CE + backward.  Leaves the SUM-loss gradient in
  * d_grads[0 : n_active) and {loss_sum, count} in d_grads[n_active], d_grads[n_active+1] so that ONE

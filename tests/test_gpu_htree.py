@@ -209,3 +209,22 @@ def test_homogeneous_htree_train_step():
         losses.append(step.loss())
     # one shared weight set for every node role learns slower than the hetero net: 3.27 -> 2.68 in 30 steps
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0] and losses[-1] < losses[10] < losses[0]
+
+
+@pytest.mark.parametrize("block,init", [("GraphSAGE", True), ("GraphSAGE", False), ("GAT", True)])
+def test_htree_two_head_task_parity(block, init):
+    """``output_dim_dict``: (rooms, objects) = LeafPool over r_to_rv / o_to_ov of the activated + dropped final states
+    (reference heterogeneous_neural_tree_network.py:186-205); second readout of the executor + the bipartite LeafPool operator"""
+    from test_gpu_models import two_head_check
+
+    torch.manual_seed(5)
+    out = {t: 26 for t in HT_DIMS if not t.endswith("_virtual")}
+    out["object"] = 35
+    kw = dict(input_dim_dict=HT_DIMS, output_dim_dict=out, conv_block=block, hidden_dim=32, num_layers=3,
+              GAT_hidden_dims=[16, 16], GAT_heads=[2, 2, 2], GAT_concats=[True, True, False],
+              disable_initialization=not init, dropout=0.0 if block == "GAT" else 0.25)
+    ora = omodels.HeterogeneousNeuralTreeNetwork(**kw)
+    net = HeterogeneousNeuralTreeNetwork(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    batch = workloads.htree_batch(4, seed=37)
+    two_head_check(ora, net.to(DEV), batch, to64(batch))

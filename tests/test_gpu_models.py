@@ -228,3 +228,93 @@ def test_cpu_tensors_are_rejected():
     _, net = sage_pair(16, 2)
     with pytest.raises(_lib.HydraMPError):
         net(small_batch(2))  # batch left on the CPU
+
+
+# ---- two-headed task (classification_task 'all': output_dim_dict) -------------------------------------------------------------
+def hetero_replay(net):
+    lib = _lib.require_device()
+
+    def replay(x, pp, training, tag):
+        if not training or pp == 0:
+            return x
+        layer, t = tag[1:].split(".", 1)
+        n, F = x.shape
+        m = torch.zeros(max(n * F, 1), dtype=torch.uint8, device=DEV)
+        if n * F:
+            _lib.check(lib.hmp_dropout_mask(net._seed, net._rng_step, net._drop_stream(int(layer), t), pp, n, F, m.data_ptr(), _lib.stream_ptr()))
+        return x * m[: n * F].view(n, F).cpu().to(x.dtype) / (1.0 - pp)
+
+    return replay
+
+
+def two_head_check(ora, net, batch, b64):
+    """forward (both outputs) and the gradients of a loss that uses both, against the oracle in float64"""
+    net.train()
+    pr, po = net(batch.to(DEV))
+    ora.dropout_fn = hetero_replay(net)
+    o64 = copy.deepcopy(ora).double().train()
+    rr, ro = o64(b64)
+    assert pr.shape == rr.shape and po.shape == ro.shape and po.shape[0] > 0 and pr.shape[1] != po.shape[1]
+    torch.testing.assert_close(pr.detach().cpu().double(), rr.detach(), atol=ATOL, rtol=RTOL)
+    torch.testing.assert_close(po.detach().cpu().double(), ro.detach(), atol=ATOL, rtol=RTOL)
+    ((rr * rr).sum() / rr.shape[0] + ro.sum() / ro.shape[0]).backward()
+    ((pr * pr).sum() / pr.shape[0] + po.sum() / po.shape[0]).backward()
+    og = dict(o64.named_parameters())
+    for name, p in net.named_parameters():
+        assert (p.grad is None) == (og[name].grad is None), name
+        if p.grad is not None:
+            torch.testing.assert_close(p.grad.cpu().double(), og[name].grad, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
+    return net, o64
+
+
+@pytest.mark.parametrize("block", ["GraphSAGE", "GAT"])
+def test_hetero_two_head_task_parity(block):
+    """``HeterogeneousNetwork(output_dim_dict=...)`` returns (rooms, objects) after activation + dropout on the final states
+    (reference heterogeneous_network.py:123-135): the executor's second readout (hmp_net_aux_output / hmp_net_backward2); every
+    last-layer conv is live, the two outputs have different widths"""
+    torch.manual_seed(2)
+    kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim_dict={"rooms": 26, "objects": 35}, conv_block=block,
+              hidden_dim=32, num_layers=3, dropout=0.25)
+    if block == "GAT":  # attention-dropout masks are not replayed here (test_gpu_gat.py covers them)
+        kw.update(GAT_hidden_dims=[16, 16], GAT_heads=[2, 2, 2], GAT_concats=[True, True, False], dropout=0.0)
+    ora = omodels.HeterogeneousNetwork(**kw)
+    net = HeterogeneousNetwork(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    batch = small_batch(5, seed=17)
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    net, o64 = two_head_check(ora, net.to(DEV), batch, b64)
+    last = f"convs.{net.num_layers - 1}."
+    for name, p in net.named_parameters():  # no last-layer conv is dead when both final states are outputs
+        assert p.grad is not None or not name.startswith(last), name
+    with pytest.raises(NotImplementedError):
+        net.train_step(lr=1e-3)
+
+
+def test_hetero_two_head_one_output_unused():
+    """a loss over ONE of the two outputs: the other's gradient enters as zeros (autograd materialises it), in either order"""
+    torch.manual_seed(3)
+    kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim_dict={"rooms": 7, "objects": 9}, conv_block="GraphSAGE",
+              hidden_dim=16, num_layers=2, dropout=0.0)
+    ora = omodels.HeterogeneousNetwork(**kw)
+    net = HeterogeneousNetwork(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net = net.to(DEV).eval()
+    batch = small_batch(3, seed=19)
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    for which in (0, 1):
+        o64 = copy.deepcopy(ora).double().eval()
+        o64(b64)[which].square().mean().backward()
+        net.zero_grad(set_to_none=True)
+        net(batch.to(DEV))[which].square().mean().backward()
+        og = dict(o64.named_parameters())
+        for name, p in net.named_parameters():
+            ref = og[name].grad
+            got = p.grad.cpu().double() if p.grad is not None else None
+            if ref is None:  # the executor's liveness is static: a conv that only feeds the unused output gets exact zeros
+                assert got is None or float(got.abs().max()) == 0.0, name
+            else:
+                torch.testing.assert_close(got, ref, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
