@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
 
 // ----- fused SAGE layer aggregation -----------------------------------------------------------------
 // out[t][i] = dropout(act( zroot[i] + bias + sum_e mean_{k in N_e(i)} z_e[col_k] ))   (one row group, result also in `tot`)
-template <int GS, int NV, bool ZB = false>
+template <int GS, int NV, bool ZB = false, bool HB = false>
 __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int c0, Acc<4> (&tot)[NV]) {
   constexpr int VEC = 4;
   // dropout coordinates incl. the device step counter: read now, not behind the gathers (one dependent round trip less)
@@ -374,7 +374,8 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
       if (D.drop_on) v = keep[i] ? (v * D.drop.scale + 0.0f) : -0.0f;  // "+ 0.0f": a kept -0.0 becomes +0.0
       tot[q].at(i) = v;
     }
-    tot[q].store(D.out + (int64_t)row * D.ldo + c);
+    if constexpr (HB && VEC == 4) store_z<true>(tot[q], D.out, (int64_t)row * D.ldo + c);
+    else tot[q].store(D.out + (int64_t)row * D.ldo + c);
   }
 }
 
@@ -422,7 +423,7 @@ __device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, in
   }
 }
 
-template <int GS, int NV, bool ZB = false>
+template <int GS, int NV, bool ZB = false, bool HB = false>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   int ti = 0;
   while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   // the label is requested before the aggregation (it depends on nothing): one round trip less behind the last gather
   int64_t y = 0;
   if (NV == 1 && D.ce_labels) y = D.ce_labels[row];
-  agg_row<GS, NV, ZB>(D, a.mean, row, c0, tot);
+  agg_row<GS, NV, ZB, HB>(D, a.mean, row, c0, tot);
   if constexpr (NV == 1) {
     if (D.ce_labels) ce_rowgroup<GS>(D, a.state, row, c0, tot[0], y);
   }
@@ -947,10 +948,12 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
   if (blocks == 0) return HMP_OK;
   if (a.zb16) {  // bf16 projected rows: only the one-wavefront-per-row shape reads them
     HMP_CHECK_ARG(gs == 64 && nv == 1, "agg_fwd: bf16 projected rows need row widths in (128, 256], got %d", Fmax);
-    hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true>), dim3(blocks), dim3(256), 0, st, a);
+    if (a.hb16) hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true>), dim3(blocks), dim3(256), 0, st, a);
     HMP_LAUNCH_CHECK();
     return HMP_OK;
   }
+  HMP_CHECK_ARG(!a.hb16, "agg_fwd: bf16 outputs need bf16 projected rows (the one-wavefront-per-row kernel)");
 #define LAUNCH_FWD(GS_, NV_) hipLaunchKernelGGL((agg_fwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_FWD)
 #undef LAUNCH_FWD

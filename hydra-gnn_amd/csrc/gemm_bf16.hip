@@ -270,7 +270,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   const bool b_al = (P.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(P.B) & 15) == 0;
   const bool a_16 = P.a_bf16 != 0;  // host guarantees: 8-byte aligned rows, whole tiles (see GemmProblem::a_bf16)
   const bool a_fast = !a_16 && a_al && (a_kc || m0 + ROWS <= P.M);
-  const bool b_fast = b_al && (b_kc || n0 + ROWS <= P.n_real);
+  const bool b_16 = P.b_bf16 != 0;  // host guarantees: n_real is whole tiles, the ones column is the ONES product (GemmProblem::b_bf16)
+  const bool b_fast = !b_16 && b_al && (b_kc || n0 + ROWS <= P.n_real);
   // virtual ones column of B (bias gradient = column sums of A over k): instead of a whole extra column tile for ONE column
   // (a third of the config-5 weight-gradient work), the first column tile's wn == 0 waves run one more MFMA per row tile
   // and k step against an all-ones operand; column 0 of that product is the column sum.
@@ -300,17 +301,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
     if (a_16) bf_load16<NT, ROWS, BKB>(ra, reinterpret_cast<const uint16_t*>(P.A), P.lda, a_kc, m0, P.M, k0, kend);
     else if (a_fast) bf_load_fast<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
     else bf_load_edge<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, P.M, 0, k0, kend);
-    if (b_fast) bf_load_fast<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
+    if (b_16) bf_load16<NT, ROWS, BKB>(rb, reinterpret_cast<const uint16_t*>(P.B), P.ldb, b_kc, n0, P.n_real, k0, kend);
+    else if (b_fast) bf_load_fast<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
     else bf_load_edge<NT, ROWS, BKB>(rb, P.B, P.ldb, b_kc, n0, P.n_real, P.n_real, P.aug_ones, k0, kend);
   };
   load(kbeg);
   for (int kt = kbeg; kt < kend; kt += BKB) {
     if (a_16) bf_mask16<NT, ROWS, BKB>(ra, a_kc, m0, P.M, kt, kend);
     else if (a_fast) bf_mask<NT, ROWS, BKB>(ra, a_kc, m0, P.M, kt, kend);
-    if (b_fast) bf_mask<NT, ROWS, BKB>(rb, b_kc, n0, P.n_real, kt, kend);
+    if (b_16) bf_mask16<NT, ROWS, BKB>(rb, b_kc, n0, P.n_real, kt, kend);
+    else if (b_fast) bf_mask<NT, ROWS, BKB>(rb, b_kc, n0, P.n_real, kt, kend);
     if (a_16) bf_store16<NT, ROWS, BKB>(ra, As, a_kc);
     else bf_store<NT, ROWS, BKB>(ra, As, a_kc);
-    bf_store<NT, ROWS, BKB>(rb, Bs, b_kc);
+    if (b_16) bf_store16<NT, ROWS, BKB>(rb, Bs, b_kc);
+    else bf_store<NT, ROWS, BKB>(rb, Bs, b_kc);
     __syncthreads();
     if (kt + BKB < kend) load(kt + BKB);
 #pragma unroll
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   const bool c16 = P.c_bf16 != 0;
   const float dscale = dropon ? P.drop.scale : 1.f;
   const float* Hp = P.H;
+  const bool h16 = P.h_bf16 != 0;  // block-uniform: the activations were stored as bf16 (sign of zero = keep bit survives)
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -354,7 +359,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
       const bool cok = col < Ncols;
       const int colc = cok ? col : 0;
       float hv[16];
-      if (amask) {
+      if (amask && h16) {  // hoisted like c16 below: no branch between the 16 loads of either form
+        const uint16_t* Hb = reinterpret_cast<const uint16_t*>(Hp);
+        uint16_t hb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          hb[r] = Hb[(int64_t)(row < Mrows ? row : Mrows - 1) * ldh + colc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = __uint_as_float((uint32_t)hb[r] << 16);
+      } else if (amask) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -421,6 +436,8 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_bf16: negative size");
     any_ones = any_ones || p.aug_ones != 0;
+    HMP_CHECK_ARG(!p.b_bf16 || ((p.n_real & 255) == 0 && (p.ldb & 3) == 0 && (!p.aug_ones || want_split)),
+                  "gemm_bf16: a bf16 B operand needs n_real %% 256 == 0 (got %d) and the split-K form for its ones column", p.n_real);
     if (want_split) {
       if (!(p.trans_a && !p.trans_b)) big = false;
       if (p.M >= 192 && p.n_real >= 192 && p.K >= (1 << 17)) tn_wide = true;

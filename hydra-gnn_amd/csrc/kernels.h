@@ -16,6 +16,9 @@ struct GemmProblem {
   const float* H;        // EPI_ACTMASK: activations whose derivative masks C (same shape as C)
   int c_bf16;            // gemm_bf16_kernel: C holds bf16 elements (ldc counts elements)
   int a_bf16;            // gemm_bf16_kernel: A holds bf16 elements (lda counts elements); every tile must take the fast loader
+  int b_bf16;            // gemm_bf16_kernel: B holds bf16 elements (activations H as the weight gradient's operand); n_real must be
+                         // whole tiles (a multiple of 256), the virtual ones column is the kernel's ONES product
+  int h_bf16;            // gemm_bf16_kernel, EPI_ACTMASK: H holds bf16 elements (ldh counts elements)
   int64_t slab_stride;   // split-K: slab z is written at C + z*slab_stride
   int M, N, K;
   int lda, ldb, ldc, ldh;
@@ -172,6 +175,7 @@ struct AggArgs {
   int mean;  // divide every gather by max(deg,1)
   int xcd;   // large launches: consecutive row ranges stay on one XCD (block counts padded to 8 per entry), see agg_fwd_launch
   int zb16;  // the projected rows (AggIn::z, AggDst::zroot) hold bf16 elements (bf16 compute mode, 256-wide rows)
+  int hb16;  // with zb16: the outputs (AggDst::out) are WRITTEN as bf16 elements too (activations of a hidden layer, read only by GEMMs)
   NetState* state;  // status bits (fused cross entropy: label out of range)
   AggDst d[HMP_MAX_NODE_TYPES];
 };

@@ -105,6 +105,7 @@ struct hmp_net {
   float* d_slabs = nullptr;
   float* H[HMP_MAX_LAYERS + 1][HMP_MAX_NODE_TYPES];
   float* G[HMP_MAX_LAYERS + 1][HMP_MAX_NODE_TYPES];
+  bool h16[HMP_MAX_LAYERS + 1][HMP_MAX_NODE_TYPES] = {};  // last forward: H[l][t] was written as bf16 (see forward_impl)
   float* Z[HMP_MAX_LAYERS][HMP_MAX_NODE_TYPES];
   float* dZ[HMP_MAX_LAYERS][HMP_MAX_NODE_TYPES];
   float* d_out = nullptr;   // pooled output [cap_out, out_ld] (only with pool_edge_type)
@@ -747,7 +748,7 @@ bool gemm_takes_bf16(const std::vector<GemmProblem>& ps, bool allow_bf16) {
 int gemm_many(std::vector<GemmProblem>& ps, bool want_split, hipStream_t st, std::vector<int>* ksplit_out, bool allow_bf16 = false) {
   bool bf16 = gemm_takes_bf16(ps, allow_bf16);
   for (const GemmProblem& p : ps)
-    if (p.a_bf16 || p.c_bf16) {  // bf16-stored operands exist only for the bf16 kernel
+    if (p.a_bf16 || p.c_bf16 || p.b_bf16 || p.h_bf16) {  // bf16-stored operands exist only for the bf16 kernel
       HMP_CHECK_ARG(allow_bf16, "net: bf16-stored GEMM operand outside bf16 compute mode");
       bf16 = true;
     }
@@ -851,6 +852,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   hipStream_t side = (n->use_branches && (n->branch_mask & 1)) ? n->side[0] : main_st;
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   n->fuse_now = fuse_small(n, b);
+  memset(n->h16, 0, sizeof(n->h16));
   // Small batches, SAGE layer 0: projection (reading the stacked weights straight from the flat parameters), plan and pack
   // are roles of ONE launch (front.hip) -- the plan, which has to read whole edge lists through single CUs, hides behind
   // the projection tiles.
@@ -883,6 +885,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         GemmProblem p;
         memset(&p, 0, sizeof(p));
         p.A = h_ptr(n, l, s); p.lda = h_ld(n, l, s); p.trans_a = 0;
+        p.a_bf16 = n->h16[l][s] ? 1 : 0;
         p.B = n->d_packed + Y.wp_off[s]; p.ldb = Y.ldw[s]; p.trans_b = 1;
         p.C = n->Z[l][s]; p.ldc = Y.ncols[s];
         p.M = b->n_nodes[s]; p.N = Y.ncols[s]; p.K = n->dim[l][s];
@@ -982,6 +985,26 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         z_done = true;
       } else {
         a.zb16 = z16 ? 1 : 0;
+        // same regime: the activations H[l+1] of a hidden layer are read only by GEMMs of the bf16 kernel (next projection, its
+        // weight gradient, the activation mask of its input gradient), which round them to bf16 on the way into LDS anyway --
+        // written as bf16 here the results are bit-identical and every one of those reads, and this write, moves half the bytes.
+        // Needs: every output of this launch exactly 256 wide (whole GEMM tiles), the next layer a SAGE layer whose three GEMMs
+        // (same M x N x K products) take the bf16 kernel by their own size -- a bf16-stored operand would otherwise force a
+        // narrow last-layer projection off the exact fp32 kernel (measured: 40 000 objects x 28 live columns)
+        bool hb = z16 && l + 1 < n->L && n->lay[l + 1].kind != HMP_CONV_GAT;
+        for (int i = 0; i < a.n && hb; ++i) hb = a.d[i].F == 256 && a.d[i].ldo == 256;
+        if (hb) {
+          double work = 0.0;
+          for (int s = 0; s < n->T; ++s) work += (double)b->n_nodes[s] * n->lay[l + 1].ncols[s] * n->dim[l + 1][s];
+          hb = work >= 1e9;  // gemm_takes_bf16's work criterion
+        }
+        const char* hv = getenv("HMP_H16");  // 0: keep fp32 activations (tests)
+        if (hv && hv[0] == '0') hb = false;
+        if (hb) {
+          a.hb16 = 1;
+          for (int t = 0; t < n->T; ++t)
+            if (Y.roff[t] >= 0 && b->n_nodes[t] > 0) n->h16[l + 1][t] = true;
+        }
         HMP_TRY(agg_fwd_launch(a, st));
       }
     }
@@ -1159,6 +1182,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           const hmp_layer_spec& Lp = S.layers[l - 1];
           p.epi = EPI_ACTMASK;
           p.H = n->H[l][s]; p.ldh = n->ld[l][s]; p.act = Lp.act;
+          p.h_bf16 = n->h16[l][s] ? 1 : 0;
           p.drop_on = (n->training && Lp.dropout > 0.f) ? 1 : 0;
           if (p.drop_on) p.drop = make_drop(n, Lp.dropout, (uint32_t)((l - 1) * HMP_MAX_NODE_TYPES + s));
           if (p.act == HMP_ACT_NONE && !p.drop_on) p.epi = EPI_NONE;
@@ -1204,6 +1228,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 1;
         p.a_bf16 = dz16 ? 1 : 0;
         p.B = h_ptr(n, l, s); p.ldb = h_ld(n, l, s); p.trans_b = 0;
+        p.b_bf16 = n->h16[l][s] ? 1 : 0;
         p.C = n->d_slabs + Y.slab_off[s]; p.ldc = Y.lddw[s];
         p.slab_stride = (int64_t)Y.ncols[s] * Y.lddw[s];
         p.M = Y.ncols[s]; p.N = n->dim[l][s] + 1; p.K = b->n_nodes[s];
@@ -1258,7 +1283,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       const char* tv = getenv("HMP_TN");  // 0: LDS-staged split-K kernel (tests)
       if (tv && tv[0] == '0') direct = false;
       for (size_t i = 0; i < wps.size() && direct; ++i)
-        if (wps[i].K > TN_DIRECT_SLABS * 384) direct = false;
+        if (wps[i].K > TN_DIRECT_SLABS * 384 || wps[i].b_bf16 || wps[i].a_bf16) direct = false;
       for (size_t base = 0; base < wps.size() && direct; base += GEMM_MAX_PROB) {
         TnBatch tb;
         memset(&tb, 0, sizeof(tb));

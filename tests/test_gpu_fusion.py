@@ -274,6 +274,40 @@ def test_bf16_compute_mode_on_a_large_graph():
     assert torch.equal(net2(small.to(DEV)), a)
 
 
+def test_bf16_mode_activation_storage_is_bit_identical():
+    """bf16 compute mode, 256-wide hidden layers: the activations H of the hidden layers are written as bf16 by the aggregation
+    and read as bf16 by the next projection, its weight gradient and the activation / dropout mask of its input gradient.
+    Those GEMMs round H to bf16 on the way into LDS anyway and the dropout keep-bit is the sign of zero, so logits and every
+    gradient must be BIT-identical to fp32-stored activations (HMP_H16=0), in training mode with dropout."""
+    kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, dropout=0.25)
+    g = workloads.big_hetero_graph(n_obj=40000, n_rooms=400, seed=9).to(DEV)
+    _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+    net.train()
+    net.native().set_compute("bf16")
+    y = g["rooms"].y
+
+    def fwd_bwd():
+        net._rng_step = 0  # same dropout masks in every run
+        for p in net.parameters():
+            p.grad = None
+        pred = net(g)
+        net.loss(pred, y, y != 25).backward()
+        return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    out, grads = fwd_bwd()
+    os.environ["HMP_H16"] = "0"
+    try:
+        out32, g32 = fwd_bwd()
+    finally:
+        del os.environ["HMP_H16"]
+    assert torch.equal(out, out32)
+    assert set(grads) == set(g32)
+    for k in grads:
+        assert torch.equal(grads[k], g32[k]), k
+    net.eval()  # and the dropout really acted (train != eval), i.e. the keep bits were read
+    assert not torch.equal(net(g), out)
+
+
 @pytest.mark.parametrize("hidden", [64, 256])
 def test_large_launch_xcd_row_mapping_is_bit_identical(hidden, monkeypatch):
     """>= 65536 rows: the aggregation kernels hand every XCD one contiguous eighth of the rows (L2 locality).  Which block
