@@ -99,7 +99,7 @@ def make_workload(args, rank):
         f"BASELINE configs[4]: ONE synthetic hetero graph per rank, {args.big_objects} objects, {max(args.big_objects // 100, 1)} rooms, "
         f"in-degree 16, 3-layer HeteroConv(SAGE) hidden 256; projections in {args.precision} MFMA with fp32 accumulation; "
         + ("fp32 storage" if args.precision == "fp32" else
-           "projected rows Z, input gradients G and dZ stored as bf16, features / activations / parameters / optimiser state fp32"))
+           "projected rows Z, input gradients G, dZ and the hidden activations H (read only by those GEMMs) stored as bf16, features / logits / parameters / optimiser state fp32"))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -301,7 +301,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands and the gathered intermediates Z / G / dZ; fp32 accumulation, activations, parameters)",
+        "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands, the gathered intermediates Z / G / dZ and the hidden activations; fp32 accumulation, logits, parameters)",
         "data": "synthetic",
         "config": {
             "workload": workload + "; training step = CSR/CSC plan + fwd + masked CE + bwd + flat-grad all-reduce + Adam",
