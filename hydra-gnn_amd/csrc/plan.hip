@@ -23,19 +23,46 @@ __device__ __forceinline__ int find_job(const int64_t* start, int n, int64_t g) 
 
 // The value an edge's atomicAdd returns is its arrival slot inside the row: it is parked (coalesced) in pos_of_eid / t_eid --
 // both are first written by the rank pass -- so that the fill pass needs no second round of 2 atomics per edge.
+// Wave-aggregated: consecutive edges of one wavefront that hit the same counter (edge lists written row by row -- a scene
+// graph's object->object edges come grouped by object -- put 16 equal keys in neighbouring lanes) form a run; the run's
+// first lane adds the run length once and hands base + offset to the others.  Any distinct slots per row will do: the rank
+// pass restores the edge order.  Unsorted lists degenerate to one atomic per lane as before (+ 3 shuffles / 2 ballots).
+__device__ __forceinline__ int run_slot(int* counter, int key, int job, bool valid) {
+  const int lane = threadIdx.x & 63;
+  const int pk = __shfl_up(key, 1), pj = __shfl_up(job, 1);
+  const bool pv = __shfl_up((int)valid, 1) != 0;
+  const bool head = valid && (lane == 0 || !pv || pk != key || pj != job);
+  const unsigned long long heads = __ballot(head), vmask = __ballot(valid);
+  const unsigned long long le = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+  const int hpos = 63 - __clzll((long long)(heads & le));  // valid lanes only: their run's head is at or below them
+  const unsigned long long stop = (heads | ~vmask) & ~le;  // next head or hole above this lane ends the run
+  const int next = stop ? __ffsll((long long)stop) - 1 : 64;
+  int base = 0;
+  if (head) base = atomicAdd(counter, next - lane);
+  base = __shfl(base, valid ? hpos : lane);
+  return base + (lane - hpos);
+}
+
 __global__ __launch_bounds__(256) void plan_hist_kernel(const PlanBatch pb, int* status) {
   const int64_t total = pb.edge_start[pb.n];
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int j = find_job(pb.edge_start, pb.n, g);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // wave-uniform trip count: every lane takes part in the shuffles of run_slot
+  for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); g0 < total; g0 += stride) {
+    const int64_t g = g0 + (threadIdx.x & 63);
+    const bool live = g < total;
+    const int j = find_job(pb.edge_start, pb.n, live ? g : total - 1);
     const PlanJob& J = pb.j[j];
-    const int64_t e = g - pb.edge_start[j];
+    const int64_t e = (live ? g : total - 1) - pb.edge_start[j];
     const int64_t s = J.ei[e], d = J.ei[J.E + e];
-    if (s < 0 || s >= J.n_src || d < 0 || d >= J.n_dst) {
-      if (status) atomicOr(status, 1);
-      continue;
+    const bool ok = s >= 0 && s < J.n_src && d >= 0 && d < J.n_dst;
+    if (live && !ok && status) atomicOr(status, 1);
+    const bool valid = live && ok;
+    const int din = run_slot(&J.cnt_in[valid ? d : 0], (int)d, j, valid);
+    const int dout = run_slot(&J.cnt_out[valid ? s : 0], (int)s, j, valid);
+    if (valid) {
+      J.pos_of_eid[e] = din;
+      J.t_eid[e] = dout;
     }
-    J.pos_of_eid[e] = atomicAdd(&J.cnt_in[d], 1);
-    J.t_eid[e] = atomicAdd(&J.cnt_out[s], 1);
   }
 }
 
