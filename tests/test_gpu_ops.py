@@ -78,6 +78,47 @@ def test_plan_bit_exact(E, n_src, n_dst):
         assert torch.equal(p["t_pos"].cpu().long()[:E], pos_of[t_order])
 
 
+@pytest.mark.parametrize("group_by", ["dst", "src"])
+@pytest.mark.parametrize("bad", [False, True])
+def test_plan_bit_exact_on_row_grouped_edge_lists(group_by, bad, monkeypatch):
+    """Edge lists written row by row (runs of 1..70 equal keys in neighbouring lanes, crossing wavefront boundaries, duplicate
+    edges) take the wave-aggregated counters of ``plan_hist_kernel``: same stable CSR / CSC as a sort; out-of-range edges inside
+    a run (holes) are dropped and flagged without disturbing their neighbours."""
+    monkeypatch.setenv("HMP_PLAN_SMALL", "0")  # the multi-launch build with global counters
+    rng = np.random.default_rng(11 if group_by == "dst" else 12)
+    n_src, n_dst = 5000, 4000
+    n_key = n_dst if group_by == "dst" else n_src
+    keys = np.repeat(rng.permutation(n_key)[:2500], rng.integers(1, 71, 2500))  # grouped, not sorted: a key never comes back
+    E = keys.size
+    other = rng.integers(0, n_src if group_by == "dst" else n_dst, E)
+    other[rng.random(E) < 0.2] = other[0]  # duplicates and long runs on the other side too
+    src, dst = (other, keys) if group_by == "dst" else (keys, other)
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    valid = torch.ones(E, dtype=torch.bool)
+    if bad:
+        holes = torch.from_numpy(rng.choice(E, 300, replace=False))
+        ei[0, holes[:100]] = n_src  # one past the end
+        ei[1, holes[100:200]] = -1
+        ei[0, holes[200:]] = -5
+        valid[holes] = False
+    p = build_plan(ei.to(dev()), n_src, n_dst)
+    assert (p["status"] & 1) == int(bad)
+    ids = torch.nonzero(valid).flatten()
+    s, d = ei[0, ids], ei[1, ids]
+    order = ids[torch.sort(d, stable=True).indices]
+    t_order = ids[torch.sort(s, stable=True).indices]
+    rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(d, minlength=n_dst), 0)
+    t_rowptr = torch.zeros(n_src + 1, dtype=torch.int64)
+    t_rowptr[1:] = torch.cumsum(torch.bincount(s, minlength=n_src), 0)
+    Ev = ids.numel()
+    assert torch.equal(p["rowptr"].cpu().long(), rowptr)
+    assert torch.equal(p["t_rowptr"].cpu().long(), t_rowptr)
+    assert torch.equal(p["eid"].cpu().long()[:Ev], order)
+    assert torch.equal(p["col"].cpu().long()[:Ev], ei[0][order])
+    assert torch.equal(p["t_col"].cpu().long()[:Ev], ei[1][t_order])
+
+
 def test_plan_multi_launch_and_single_launch_builds_agree(monkeypatch):
     """HMP_PLAN_SMALL pins the build: 0 = histogram/scan/fill/rank launches with global counters, 1 = one launch (LDS)"""
     rng = np.random.default_rng(77)
