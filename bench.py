@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="1 GPU only: run the data-parallel launch structure (un-pack, RCCL all-reduce in a 1-rank group, Adam) "
                          "to price the collective path without a second GPU; diagnosis, not the bench line")
+    ap.add_argument("--edge-order", choices=["grouped", "random"], default="grouped",
+                    help="config 5: 'grouped' = edge lists as the generator writes them, destination by destination (the order a "
+                         "scene-graph builder produces); 'random' = every edge list permuted (worst case of the plan's "
+                         "wave-aggregated counters; results are identical, the plan restores the stable order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -95,6 +99,11 @@ def make_workload(args, rank):
     kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3,
               dropout=0.25)
     g = workloads.big_hetero_graph(n_obj=args.big_objects, n_rooms=max(args.big_objects // 100, 1), seed=workloads.BASE_SEED + 5 + rank)
+    if args.edge_order == "random":
+        gen = torch.Generator().manual_seed(1234 + rank)
+        for et in g.edge_types:
+            ei = g[et].edge_index
+            g[et].edge_index = ei[:, torch.randperm(ei.size(1), generator=gen)].contiguous()
     return kw, "HeterogeneousNetwork", g, "rooms", (
         f"BASELINE configs[4]: ONE synthetic hetero graph per rank, {args.big_objects} objects, {max(args.big_objects // 100, 1)} rooms, "
         f"in-degree 16, 3-layer HeteroConv(SAGE) hidden 256; projections in {args.precision} MFMA with fp32 accumulation; "
@@ -304,7 +313,8 @@ def main():
         "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands, the gathered intermediates Z / G / dZ and the hidden activations; fp32 accumulation, logits, parameters)",
         "data": "synthetic",
         "config": {
-            "workload": workload + "; training step = CSR/CSC plan + fwd + masked CE + bwd + flat-grad all-reduce + Adam",
+            "workload": workload + ("; edge lists randomly permuted" if args.config == 5 and args.edge_order == "random" else "")
+            + "; training step = CSR/CSC plan + fwd + masked CE + bwd + flat-grad all-reduce + Adam",
             "graphs_per_rank": n_graphs,
             "global_batch": n_graphs * world,
             "nodes_per_rank": dict(zip(nat.node_types, step._holder.n_nodes if step._holder else [])),
