@@ -297,8 +297,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
   StageRegs<ROWS * BKB / 4 / NT> ra, rb;
+  // A in two pieces (a_split): [k][row] images (weight gradient) pick the piece per row tile, [row][k] images (input
+  // gradient) per K stage; the second base is moved back by a_split elements so that the loaders keep their global indices
+  const uint16_t* A16 = reinterpret_cast<const uint16_t*>(P.A);
+  const uint16_t* A16b = reinterpret_cast<const uint16_t*>(P.A2) - P.a_split;
+  const bool a_two = a_16 && P.a_split > 0;
+  const bool a_tile2 = a_two && !a_kc && m0 >= P.a_split;  // block-uniform
   auto load = [&](int k0) {
-    if (a_16) bf_load16<NT, ROWS, BKB>(ra, reinterpret_cast<const uint16_t*>(P.A), P.lda, a_kc, m0, P.M, k0, kend);
+    if (a_16) {
+      const bool second = a_tile2 || (a_two && a_kc && k0 >= P.a_split);
+      bf_load16<NT, ROWS, BKB>(ra, second ? A16b : A16, second ? P.lda2 : P.lda, a_kc, m0, P.M, k0, kend);
+    }
     else if (a_fast) bf_load_fast<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
     else bf_load_edge<NT, ROWS, BKB>(ra, P.A, P.lda, a_kc, m0, P.M, P.M, 0, k0, kend);
     if (b_16) bf_load16<NT, ROWS, BKB>(rb, reinterpret_cast<const uint16_t*>(P.B), P.ldb, b_kc, n0, P.n_real, k0, kend);
@@ -436,6 +445,8 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_bf16: negative size");
     any_ones = any_ones || p.aug_ones != 0;
+    HMP_CHECK_ARG(p.a_split == 0 || (p.a_bf16 && p.A2 && (p.a_split & 255) == 0 && (p.lda2 & 3) == 0),
+                  "gemm_bf16: a two-piece A needs bf16 pieces and a split at a multiple of 256 (got %d)", p.a_split);
     HMP_CHECK_ARG(!p.b_bf16 || ((p.n_real & 255) == 0 && (p.ldb & 3) == 0 && (!p.aug_ones || want_split)),
                   "gemm_bf16: a bf16 B operand needs n_real %% 256 == 0 (got %d) and the split-K form for its ones column", p.n_real);
     if (want_split) {

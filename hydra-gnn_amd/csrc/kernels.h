@@ -19,6 +19,9 @@ struct GemmProblem {
   int b_bf16;            // gemm_bf16_kernel: B holds bf16 elements (activations H as the weight gradient's operand); n_real must be
                          // whole tiles (a multiple of 256), the virtual ones column is the kernel's ONES product
   int h_bf16;            // gemm_bf16_kernel, EPI_ACTMASK: H holds bf16 elements (ldh counts elements)
+  const float* A2;       // gemm_bf16_kernel with a_bf16: the slice of A from index a_split on (along its row-contiguous / K
+  int lda2, a_split;     // axis: columns of dZ) lives in a second bf16 matrix -- the root block of dZ IS the output gradient,
+                         // so nobody copies it.  a_split > 0 and a multiple of 256; 0: A is one matrix
   int64_t slab_stride;   // split-K: slab z is written at C + z*slab_stride
   int M, N, K;
   int lda, ldb, ldc, ldh;

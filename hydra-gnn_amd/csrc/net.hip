@@ -1075,6 +1075,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       return n->G[l + 1][t];
     };
     bool dx_fused = false;
+    bool rootless = false;  // this layer's GEMMs take the root block of dZ from the output gradient
     dz16 = false;
     if (Y.kind == HMP_CONV_GAT) {
       Scope sc(n, KC_GAT_BWD, st);
@@ -1151,6 +1152,18 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           if (zv && zv[0] == '0') dz16 = false;
         }
         a.dzb16 = dz16 ? 1 : 0;
+        // the root block of dZ is a copy of the output gradient (d out / d z_root = 1): with both stored as bf16 and the block
+        // on a 256-column boundary the two backward GEMMs read it where it is (GemmProblem::A2) and the copy -- 1 GB per layer
+        // at 10^6 rows -- is not made
+        rootless = dz16;
+        for (int i = 0; i < a.n && rootless; ++i)
+          if (a.s[i].groot && ((a.s[i].roff & 255) != 0 || a.s[i].Froot != 256 || (a.s[i].ldgr & 3) != 0)) rootless = false;
+        {
+          const char* rv = getenv("HMP_ROOTCOPY");  // 1: keep the copy (tests)
+          if (rv && rv[0] == '1') rootless = false;
+        }
+        if (rootless)
+          for (int i = 0; i < a.n; ++i) a.s[i].groot = nullptr;
         HMP_TRY(agg_bwd_launch(a, st));
       }
     }
@@ -1174,6 +1187,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         memset(&p, 0, sizeof(p));
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 0;
         p.a_bf16 = dz16 ? 1 : 0;
+        if (rootless && Y.roff[s] >= 0) { int ldg; p.A2 = g_of(s, ldg); p.lda2 = ldg; p.a_split = Y.roff[s]; }
         p.B = n->d_packed + Y.wp_off[s]; p.ldb = Y.ldw[s]; p.trans_b = 0;
         p.C = dst; p.ldc = l > 0 ? n->ld[l][s] : b->ldx[s];
         p.M = b->n_nodes[s]; p.N = n->dim[l][s]; p.K = Y.ncols[s];
@@ -1227,6 +1241,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         memset(&p, 0, sizeof(p));
         p.A = n->dZ[l][s]; p.lda = Y.ncols[s]; p.trans_a = 1;
         p.a_bf16 = dz16 ? 1 : 0;
+        if (rootless && Y.roff[s] >= 0) { int ldg; p.A2 = g_of(s, ldg); p.lda2 = ldg; p.a_split = Y.roff[s]; }
         p.B = h_ptr(n, l, s); p.ldb = h_ld(n, l, s); p.trans_b = 0;
         p.b_bf16 = n->h16[l][s] ? 1 : 0;
         p.C = n->d_slabs + Y.slab_off[s]; p.ldc = Y.lddw[s];

@@ -304,6 +304,16 @@ def test_bf16_mode_activation_storage_is_bit_identical():
     assert set(grads) == set(g32)
     for k in grads:
         assert torch.equal(grads[k], g32[k]), k
+    # same for the root block of dZ: by default the backward GEMMs read it straight from the bf16 output gradient
+    # (GemmProblem::A2), with HMP_ROOTCOPY=1 the transposed aggregation copies it into dZ first -- the same bits either way
+    os.environ["HMP_ROOTCOPY"] = "1"
+    try:
+        outc, gc = fwd_bwd()
+    finally:
+        del os.environ["HMP_ROOTCOPY"]
+    assert torch.equal(out, outc)
+    for k in grads:
+        assert torch.equal(grads[k], gc[k]), k
     net.eval()  # and the dropout really acted (train != eval), i.e. the keep bits were read
     assert not torch.equal(net(g), out)
 
