@@ -114,7 +114,7 @@ def make_workload(args, rank):
 # ------------------------------------------------------------------------------------------------------------
 # algorithmic (compulsory) traffic / flops of one training step, per kernel family
 # ------------------------------------------------------------------------------------------------------------
-def step_costs(net, holder, fused):
+def step_costs(net, holder, fused, root_in_place=False):
     """Algorithmic (compulsory) bytes / flops of ONE step per kernel class, from the shapes of this batch (fp32 = 4 bytes;
     formulas: DESIGN.md section 5).  `fused` = the small-batch launch sequence ran (front kernel,
     projections / input gradients inside the aggregation kernels): the GEMM terms are then charged to the kernels that
@@ -199,7 +199,10 @@ def step_costs(net, holder, fused):
             cost["agg_fwd"]["launches"] += 1
             # backward: transposed aggregation (same compulsory traffic as forward, mirrored)
             add("agg_bwd", sum(4.0 * (nn_[c.edge_type[0]] + 1) + 8.0 * ne[c.edge_type] + 4.0 * nn_[c.edge_type[2]] * al4(c.f_out)
-                               + 4.0 * nn_[c.edge_type[0]] * al4(c.f_out) for c in live) + sum(8.0 * nn_[t] * al4(layer.out_dims[t]) for t in dsts),
+                               + 4.0 * nn_[c.edge_type[0]] * al4(c.f_out) for c in live)
+                # root block of dZ = copy of the output gradient; bf16 mode at 10^6 rows: read in place by the GEMMs, no copy
+                + (0.0 if (root_in_place and l < L - 1 and all(al4(layer.out_dims[t]) == 256 for t in dsts))
+                   else sum(8.0 * nn_[t] * al4(layer.out_dims[t]) for t in dsts)),
                 sum(2.0 * ne[c.edge_type] * al4(c.f_out) for c in live))
             cost["agg_bwd"]["launches"] += 1
         # weight gradient dWp = dZ^T [H | 1]  and (l > 0) input gradient dH = dZ * Wp
@@ -353,7 +356,7 @@ def main():
         scopes_per_step = sum(v[1] for v in per.values()) / float(prof_steps)
         scopes_ms = sum(v[0] for v in per.values()) / float(prof_steps)
         event_overhead_us = max(0.0, 1e3 * (scopes_ms - out["ms_per_step"]) / max(scopes_per_step, 1.0))
-        cost = step_costs(nat, prof_step._holder, fused)
+        cost = step_costs(nat, prof_step._holder, fused, root_in_place=(args.config == 5 and args.precision == "bf16" and os.environ.get("HMP_ROOTCOPY") != "1" and os.environ.get("HMP_Z16") != "0"))
         fam = {
             "front": ("front_kernel (layer-0 projection tiles + plan parts + pack blocks, one launch)", *per["front"]),
             "gemm_fwd": ("gemm_kernel (fp32 MFMA 32x32x2, grouped, LDS-staged)", *per["gemm_fwd"]),

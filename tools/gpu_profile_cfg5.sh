@@ -1,6 +1,8 @@
+# config-5 measurement set (run through gpurun from the repo root): tools/gpu_profile_cfg5.sh <tag> -> gpurun_out/<tag>/{stats5,pmc5_fetch,pmc5_write}
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r01_n
+TAG=${1:-run5}
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -o s -- python3 $ROOT/bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats5.log 2>&1 &&
