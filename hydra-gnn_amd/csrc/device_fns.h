@@ -61,8 +61,8 @@ __device__ __forceinline__ void pack_item(const PackSeg& S, int item, const floa
 // One pack block (256 threads): one wavefront per item; `blk` indexes the SegBlocks table (4 items per block).
 // Block 0 also starts the step: it bumps the device step counter that dropout and Adam read later in the same step.
 __device__ __forceinline__ void pack_block(const PackSeg* __restrict__ segs, const SegBlocks& sb, const float* __restrict__ params,
-                                           float* __restrict__ packed, NetState* step_state, int blk) {
-  if (step_state && blk == 0 && threadIdx.x == 0) step_state->step += 1;
+                                           float* __restrict__ packed, int* step_ctr, int blk) {
+  if (step_ctr && blk == 0 && threadIdx.x == 0) *step_ctr += 1;
   int si = 0;
   while (si + 1 < sb.n && blk >= sb.start[si + 1]) ++si;  // wave-uniform scan of the kernarg table
   const PackSeg S = segs[si];

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
   }
   // pack role: 16 items per block; the block -> (segment, first item) map is a static device table
   const int kb = blk - a.gemm_blocks - a.plan_blocks;
-  if (a.state && kb == 0 && threadIdx.x == 0) a.state->step += 1;
+  if (a.step_ctr && kb == 0 && threadIdx.x == 0) *a.step_ctr += 1;
   const int2 m = a.pack_map[kb];
   pack_item(a.segs[m.x], m.y + (int)(threadIdx.x >> 6), a.params, a.packed);
 }

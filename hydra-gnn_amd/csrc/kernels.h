@@ -83,7 +83,7 @@ struct FrontArgs {
   const PackSeg* segs;
   const int2* pack_map;  // per pack block: {segment, first item}; 16 items (packed row, 64-column chunk) per block
   float* packed;
-  NetState* state;       // non-null: the pack role's first block bumps the step counter
+  int* step_ctr;         // non-null: the pack role's first block bumps this device step counter
   int part_start[2 * HMP_MAX_EDGE_TYPES + 1];
   int rows_per_part[2 * HMP_MAX_EDGE_TYPES];
   FrontJob job[HMP_MAX_EDGE_TYPES];
@@ -253,8 +253,8 @@ struct SegBlocks {
   int n;
   int start[SEG_MAX + 1];
 };
-// step_state != null: block 0 increments step_state->step (the fused step starts with the pack)
-int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, NetState* step_state, hipStream_t st);
+// step_ctr != null: block 0 increments *step_ctr (the fused step starts with the pack)
+int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, int* step_ctr, hipStream_t st);
 
 // A parameter gradient element (r, c) is the sum of up to 3 terms read from split-K slabs S (summed over slabs):
 //  GT_COPY       S[(r/C*Cp + r%C) * ld + c]                         (rows of the stacked operand; C = Cp: identity)
@@ -381,7 +381,8 @@ int grad_reduce_launch(const GradSeg* d_segs, const SegBlocks& sb, const GradRed
 // loss / adam
 // ---------------------------------------------------------------------------------------------
 struct NetState {  // device resident
-  int step;        // fused steps started so far (bumped by the pack kernel at the head of every step)
+  int step;        // fused steps started so far (bumped by the pack kernel at the head of every step) -- the net's OWN counter;
+                   // an optimiser that keeps Adam moments passes its own counter (hmp_train_args::d_step)
   int status;      // bit 0: edge endpoint out of range, bit 1: label out of range
   float loss_sum, count;
 };

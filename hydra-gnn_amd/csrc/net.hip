@@ -98,7 +98,8 @@ struct hmp_net {
   bool bound = false;
   int cap_nodes[HMP_MAX_NODE_TYPES];
   int64_t cap_edges[HMP_MAX_EDGE_TYPES];
-  NetState* d_state = nullptr;
+  NetState* d_state = nullptr;  // owned by the net (NOT part of the re-bindable workspace): status bits and the net's own step counter
+  int* d_step = nullptr;        // the step counter of the running step: the optimiser's (hmp_train_args::d_step) or &d_state->step
   hmp_plan plan[HMP_MAX_EDGE_TYPES];
   int* plan_scratch[HMP_MAX_EDGE_TYPES];
   float* d_packed = nullptr;
@@ -118,7 +119,7 @@ struct hmp_net {
   int training = 0;
   uint64_t seed = 0;
   uint32_t rng_step = 0;
-  bool step_dev = false;  // dropout step offset read from d_state->step
+  bool step_dev = false;  // dropout step offset read from *d_step
   GradReduceDyn dyn;
 
   // parallel branches (side streams; under capture they become branches of the hipGraph)
@@ -484,7 +485,6 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
     return p;
   };
   const hmp_net_spec& S = n->spec;
-  n->d_state = (NetState*)take(sizeof(NetState));
   for (int e = 0; e < n->ET; ++e) {
     const int ns = cn[S.edge_src[e]], nd = cn[S.edge_dst[e]];
     hmp_plan& P = n->plan[e];
@@ -649,7 +649,7 @@ DropCfg make_drop(const hmp_net* n, float p, uint32_t stream) {
   d.k0 = (uint32_t)n->seed; d.k1 = (uint32_t)(n->seed >> 32);
   d.step = n->rng_step; d.stream = stream;
   d.thresh = drop_thresh(p); d.scale = 1.f / (1.f - p);
-  d.step_dev = n->step_dev ? &n->d_state->step : nullptr;
+  d.step_dev = n->step_dev ? n->d_step : nullptr;
   return d;
 }
 
@@ -661,7 +661,7 @@ GatDyn make_gat_dyn(const hmp_net* n, const hmp_batch* b) {
   d.training = n->training;
   d.k0 = (uint32_t)n->seed; d.k1 = (uint32_t)(n->seed >> 32);
   d.step = n->rng_step;
-  d.step_dev = n->step_dev ? &n->d_state->step : nullptr;
+  d.step_dev = n->step_dev ? n->d_step : nullptr;
   return d;
 }
 
@@ -837,7 +837,7 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
   fa.pack_map = n->d_pack_map;
   fa.pack_blocks = n->n_pack_blocks16;
   fa.packed = n->d_packed;
-  fa.state = n->step_dev ? n->d_state : nullptr;
+  fa.step_ctr = n->step_dev ? n->d_step : nullptr;
   return true;
 }
 
@@ -867,7 +867,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     }
   } else {
     Scope sc(n, KC_PACK, side);
-    HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_state : nullptr, side));
+    HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_step : nullptr, side));
   }
   bool z_done = false;
   for (int l = 0; l < n->L; ++l) {
@@ -1347,6 +1347,15 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
   int r = build_layout(n);
   if (r == HMP_OK) r = build_tables(n);
   if (r == HMP_OK) {
+    // step counter + status bits live outside the workspace: a re-bind (a larger batch arrived) must not restart Adam's t or
+    // the dropout sequence, nor lose status bits
+    if (hipMalloc(&n->d_state, 256) != hipSuccess || hipMemset(n->d_state, 0, 256) != hipSuccess) {
+      snprintf(err_buf(), 512, "hmp_net_create: device allocation of the net state failed");
+      r = HMP_E_HIP;
+    }
+    n->d_step = n->d_state ? &n->d_state->step : nullptr;
+  }
+  if (r == HMP_OK) {
     // side-stream branches (pack + layer-0 projection next to the plan, weight gradients next to the backward chain) only
     // on request: measured on MI355X, every fork/join costs ~10 us of dependency latency, more than the overlap buys once
     // the plan is a single launch
@@ -1378,6 +1387,7 @@ extern "C" void hmp_net_destroy(hmp_net* n) {
   for (int i = 0; i < n->n_evs; ++i) (void)hipEventDestroy(n->evs[i]);
   for (int i = 0; i < 2; ++i)
     if (n->side[i]) (void)hipStreamDestroy(n->side[i]);
+  if (n->d_state) (void)hipFree(n->d_state);
   if (n->d_pack_segs) (void)hipFree(n->d_pack_segs);
   if (n->d_pack_map) (void)hipFree(n->d_pack_map);
   if (n->d_grad_segs) (void)hipFree(n->d_grad_segs);
@@ -1457,6 +1467,7 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
   HMP_CHECK_ARG(batch->d_labels != nullptr, "hmp_net_step_fwd_bwd: labels required");
   hipStream_t st = (hipStream_t)stream;
   n->training = args->training; n->seed = args->seed; n->rng_step = 0; n->step_dev = true;
+  n->d_step = args->d_step ? args->d_step : &n->d_state->step;
   n->ce_labels = batch->d_labels; n->ce_ignored = args->ignored_label; n->ce_done = false;
   const int rf = forward_impl(n, batch, d_params, st);
   n->ce_labels = nullptr;
@@ -1479,7 +1490,7 @@ extern "C" int hmp_net_step_fused(hmp_net* n, const hmp_batch* batch, float* d_p
   af.on = n->fuse_mode == 0 ? 0 : 1;
   af.p = d_params; af.m = d_m; af.v = d_v;
   af.lr = args->lr; af.b1 = args->beta1; af.b2 = args->beta2; af.eps = args->eps; af.wd = args->weight_decay;
-  af.step_dev = &n->d_state->step;
+  af.step_dev = args->d_step ? args->d_step : &n->d_state->step;
   af.count = d_grads + n->spec.n_active_params + 1;
   n->adam_done = false;
   const int r = hmp_net_step_fwd_bwd(n, batch, d_params, d_grads, args, stream);
@@ -1498,14 +1509,16 @@ extern "C" int hmp_net_step_adam(hmp_net* n, float* d_params, const float* d_gra
   Scope sc(n, KC_ADAM, st);
   // t = the step counter the pack kernel bumped at the head of this step
   return adam_launch(d_params, d_grads, d_m, d_v, na, args->lr, args->beta1, args->beta2, args->eps, args->weight_decay, 0,
-                     &n->d_state->step, d_grads + na + 1, st);
+                     args->d_step ? args->d_step : &n->d_state->step, d_grads + na + 1, st);
 }
 
 extern "C" int hmp_net_read_state(hmp_net* n, int32_t* step, int32_t* status, void* stream) {
-  HMP_CHECK_ARG(n && n->bound, "hmp_net_read_state: net not bound");
+  HMP_CHECK_ARG(n && n->d_state, "hmp_net_read_state: null net");
   NetState h;
   HMP_HIP(hipStreamSynchronize((hipStream_t)stream));
   HMP_HIP(hipMemcpy(&h, n->d_state, sizeof(h), hipMemcpyDeviceToHost));
+  if (n->d_step && n->d_step != &n->d_state->step)  // the last step counted on its optimiser's counter
+    HMP_HIP(hipMemcpy(&h.step, n->d_step, sizeof(int), hipMemcpyDeviceToHost));
   if (step) *step = h.step;
   if (status) *status = h.status;
   return HMP_OK;

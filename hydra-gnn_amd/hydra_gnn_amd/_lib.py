@@ -84,7 +84,7 @@ class Batch(C.Structure):
 class TrainArgs(C.Structure):
     _fields_ = [
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
-        ("ignored_label", C.c_int64), ("seed", C.c_uint64), ("training", C.c_int32),
+        ("ignored_label", C.c_int64), ("seed", C.c_uint64), ("training", C.c_int32), ("d_step", C.c_void_p),
     ]
 
 
@@ -148,6 +148,11 @@ SIGNATURES = {
     "hmp_rowdot_sum": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP]),
     "hmp_batchnorm_fwd": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _F32, _F32, _I32, _VP, _I32, _VP, _VP]),
     "hmp_batchnorm_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP, _I32, _VP, _VP, _VP]),
+    "hmp_comm_unique_id": (C.c_int, [_VP]),
+    "hmp_comm_create": (C.c_int, [_VP, _I32, _I32, C.POINTER(_VP)]),
+    "hmp_comm_destroy": (None, [_VP]),
+    "hmp_comm_allreduce_sum_f32": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "hmp_comm_broadcast_f32": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -59,6 +59,9 @@ class _BatchHolder:
         self.keep: List[torch.Tensor] = []
         self.n_nodes: List[int] = []
         self.n_edges: List[int] = []
+        # an input had to be copied (dtype / layout conversion): the descriptor points at a private copy, so it must not be
+        # reused for a later step (in-place edits of the caller's tensor would be missed)
+        self.converted = False
 
 
 class NativeNet:
@@ -255,6 +258,7 @@ class NativeNet:
                 _require_cuda(x, f"x_dict['{t}']")
                 if x.dtype != torch.float32 or x.stride(-1) != 1 or (x.dim() == 2 and x.size(0) > 1 and x.stride(0) < x.size(1)):
                     x = x.to(torch.float32).contiguous()
+                    h.converted = True
                 if x.size(1) != self.in_dims[t]:
                     raise _lib.HydraMPError(f"x_dict['{t}'] has {x.size(1)} features, model expects {self.in_dims[t]}")
                 h.keep.append(x)
@@ -270,11 +274,18 @@ class NativeNet:
                 _require_cuda(ei, f"edge_index_dict[{e}]")
                 if ei.dtype != torch.int64 or not ei.is_contiguous():
                     ei = ei.to(torch.int64).contiguous()
+                    h.converted = True
                 h.keep.append(ei)
                 h.c.n_edges[i] = ei.size(1)
                 h.c.d_edge_index[i] = ei.data_ptr() if ei.size(1) > 0 else None
             else:
-                h.c.n_edges[i] = 0  # absent edge type == no edges: convs over it contribute root/bias only
+                # PyG's HeteroConv SKIPS a conv whose edge type is absent from the dict (no root / bias term, smaller group-mean
+                # divisor), which differs from a present-but-empty `[2, 0]` edge_index.  The reference's loaders always
+                # materialise every type (`fill_missing_edge_index`, mp3d_dataset.py:220-255); the executor's stacked operands
+                # are built for the full conv set, so an absent key is refused instead of silently computing something else.
+                raise _lib.HydraMPError(
+                    f"edge_index_dict has no entry for {e}: pass an empty [2, 0] int64 edge_index for edge types without "
+                    "edges (the reference does: fill_missing_edge_index, mp3d_dataset.py:220-255)")
             h.n_edges.append(int(h.c.n_edges[i]))
         if self.edge_dims:
             ea_dict = data.edge_attr_dict
@@ -288,6 +299,7 @@ class NativeNet:
                 _require_cuda(ea, f"edge_attr_dict[{e}]")
                 if ea.dtype != torch.float32 or not ea.is_contiguous():
                     ea = ea.to(torch.float32).contiguous()
+                    h.converted = True
                 if ea.dim() != 2 or ea.size(0) != h.n_edges[i] or ea.size(1) != d:
                     raise _lib.HydraMPError(f"edge_attr_dict[{e}] must be [{h.n_edges[i]}, {d}], got {tuple(ea.shape)}")
                 h.keep.append(ea)
@@ -298,6 +310,8 @@ class NativeNet:
         if labels is not None:
             _require_cuda(labels, "labels")
             lab = labels.to(torch.int64).contiguous()
+            if lab is not labels:
+                h.converted = True
             if lab.numel() != h.c.n_out:
                 raise _lib.HydraMPError(f"{lab.numel()} labels for {h.c.n_out} output rows")
             h.keep.append(lab)
@@ -322,6 +336,7 @@ class NativeNet:
         self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _lib.check(self._lib.hmp_net_bind_workspace(handle, self._ws.data_ptr(), nbytes, cn_c, ce_c))
         self._caps = (cn, ce)
+        self._fwd_token += 1  # activations of an earlier forward are gone: its backward must fail loudly
 
     def _ws_view(self, ptr: int, rows: int, ld: int) -> torch.Tensor:
         off = ptr - self._ws.data_ptr()
@@ -442,8 +457,11 @@ class TrainStep:
 
     def __init__(self, net: NativeNet, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignored_label: int = 25, seed: int = 0, training: bool = True, use_graph: bool = True,
-                 process_group=None, force_collective: bool = False, view=None):
+                 process_group=None, force_collective: bool = False, view=None, comm=None, broadcast_init: bool = True):
         self.net = net
+        # comm: parallel.NativeComm -- the all-reduce is enqueued by the library on the executor's own stream (RCCL);
+        # process_group (True = default group): the same collective through torch.distributed (its own stream + event waits)
+        self.comm = comm
         # homogeneous models: callable that presents their `Data` through the hetero accessors the executor reads
         self.view = view
         # run the data-parallel launch structure (two graphs around one all-reduce) even with a single rank
@@ -460,11 +478,26 @@ class TrainStep:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        # Adam's t (and the dropout draw number) belong to the optimiser state, like m / v (torch.optim.Adam keeps
+        # state['step'] per optimiser): a second TrainStep on the same net starts at t = 1, and a workspace re-bind
+        # (a larger batch arrived) leaves it alone
+        self.step_ctr = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.args.d_step = self.step_ctr.data_ptr()
         self._holder = None
         self._batch_key = None
         self._data_ref = None
+        if broadcast_init and self._world() > 1:
+            # every rank starts from rank 0's weights: identical seeds are not relied upon
+            if self.comm is not None:
+                self.comm.broadcast_(self.flat, net.n_params)
+            else:
+                from . import parallel
+
+                parallel.broadcast_parameters(self.flat, group=None if self.pg is True else self.pg)
 
     def _world(self) -> int:
+        if self.comm is not None:
+            return self.comm.world
         if self.pg is None:
             return 1
         import torch.distributed as dist
@@ -472,6 +505,10 @@ class TrainStep:
         return dist.get_world_size(self.pg if self.pg is not True else None)
 
     def _all_reduce(self) -> None:
+        if self.comm is not None:
+            if self.comm.world > 1 or self.force_collective:
+                self.comm.all_reduce_sum_(self.grads, self.net.n_active + 2)
+            return
         if self._world() > 1 or self.force_collective:
             from . import parallel
 
@@ -506,11 +543,12 @@ class TrainStep:
             h = self._holder
         else:
             h = net.make_batch(self.view(data) if self.view is not None else data, labels)
-            self._batch_key = key
+            self._batch_key = key if not h.converted else None
             self._data_ref = (data, labels)  # keeps id() unique while the key is live
         dev = self.flat.device
         with torch.cuda.device(dev):
             net._ensure_workspace(h, dev)
+            net._fwd_token += 1  # the step overwrites the activations of any earlier forward()
             if not self.use_graph:
                 st = _lib.stream_ptr()
                 if self._world() == 1 and not self.force_collective:
@@ -575,6 +613,18 @@ class TrainStep:
             self._destroy_graphs()
         except Exception:
             pass
+
+    def set_lr(self, lr: float) -> None:
+        """Follow a learning-rate scheduler (``StepLR`` in ``base_training_job.py:186-188``): takes effect with the next
+        step.  Captured graphs carry the rate as a kernel argument and are re-captured."""
+        if C.c_float(float(lr)).value != self.args.lr:
+            self.args.lr = float(lr)
+            self._destroy_graphs()
+            self._key = None
+
+    def steps_taken(self) -> int:
+        """Adam's t after the last step (synchronises)."""
+        return int(self.step_ctr[0].item())
 
     def loss(self) -> float:
         """mean CE over the valid labels of the last step (global when data parallel); synchronises."""

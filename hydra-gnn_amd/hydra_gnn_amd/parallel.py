@@ -62,3 +62,76 @@ def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0) -> None:
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+class NativeComm:
+    """RCCL communicator owned by ``libhydra_mp.so`` (``hmp_comm_*``, csrc/comm.hip): the step's ONE all-reduce is enqueued
+    on the stream the step's kernels run on, between the two native phases -- no second stream and no event hand-offs as in
+    torch's ProcessGroupNCCL.  torch.distributed is only the rendezvous channel for the 128-byte unique id.
+
+    ``NativeComm.from_process_group()`` needs an initialised default process group (any backend); a 1-rank communicator
+    (``NativeComm.single()``) prices the collective path on one GPU."""
+
+    def __init__(self, handle, rank: int, world: int):
+        self._h, self.rank, self.world = handle, rank, world
+
+    @classmethod
+    def single(cls) -> "NativeComm":
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.require_device()
+        buf = (C.c_ubyte * 128)()
+        _lib.check(lib.hmp_comm_unique_id(buf))
+        h = C.c_void_p()
+        _lib.check(lib.hmp_comm_create(buf, 0, 1, C.byref(h)))
+        return cls(h, 0, 1)
+
+    @classmethod
+    def from_process_group(cls, device: torch.device, group=None) -> "NativeComm":
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import _lib
+
+        lib = _lib.require_device()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(lib.hmp_comm_unique_id(buf))
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=device if on_gpu else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ids = bytes(t.cpu().tolist())
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.hmp_comm_create(ids, rank, world, C.byref(h)))
+        return cls(h, rank, world)
+
+    def all_reduce_sum_(self, buf: torch.Tensor, n: int) -> None:
+        """sum ``buf[:n]`` (fp32, device) over the ranks, in place, on torch's CURRENT stream."""
+        from . import _lib
+
+        assert buf.dtype == torch.float32 and buf.is_cuda and buf.is_contiguous() and 0 <= n <= buf.numel()
+        _lib.check(_lib.load().hmp_comm_allreduce_sum_f32(self._h, buf.data_ptr(), int(n), _lib.stream_ptr()))
+
+    def broadcast_(self, buf: torch.Tensor, n: int, root: int = 0) -> None:
+        from . import _lib
+
+        assert buf.dtype == torch.float32 and buf.is_cuda and buf.is_contiguous() and 0 <= n <= buf.numel()
+        _lib.check(_lib.load().hmp_comm_broadcast_f32(self._h, buf.data_ptr(), int(n), int(root), _lib.stream_ptr()))
+
+    def close(self) -> None:
+        if self._h is not None:
+            from . import _lib
+
+            _lib.load().hmp_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -31,6 +31,7 @@ extern "C" {
 #define HMP_E_HIP 2      /* a HIP runtime call failed */
 #define HMP_E_STATE 3    /* call order violated (e.g. backward without forward) */
 #define HMP_E_NODEVICE 4 /* no gfx950 device visible */
+#define HMP_E_UNSUPPORTED 5 /* an optional system library (RCCL) is not present on this machine */
 
 #define HMP_MAX_NODE_TYPES 8
 #define HMP_MAX_EDGE_TYPES 16
@@ -227,6 +228,10 @@ typedef struct hmp_train_args {
   int64_t ignored_label;
   uint64_t seed;
   int32_t training;          /* dropout on */
+  int32_t* d_step;           /* device int32 owned by the optimiser state (next to Adam's m / v): the step counter t that
+                              * Adam's bias correction and the dropout stream read; bumped once at the head of every
+                              * step.  NULL: the net's own counter (one optimiser per net).  torch.optim.Adam keeps
+                              * `state['step']` per optimiser in the same way (base_training_job.py:181-185) */
 } hmp_train_args;
 
 typedef struct hmp_net hmp_net; /* opaque */
@@ -353,6 +358,23 @@ int hmp_object_edges_count(const double* d_pos, const double* d_size, const int3
                            double max_near, double max_on, int32_t* d_count, int32_t* d_offset, void* stream);
 int hmp_object_edges_fill(const double* d_pos, const double* d_size, const int32_t* d_room, int32_t n, double threshold_near,
                           double max_near, double max_on, const int32_t* d_offset, int32_t* d_edges, int32_t total, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 11. Data-parallel gradient exchange (csrc/comm.hip).  The reference has no multi-GPU code; a batch is a
+ *     disjoint union of scene graphs (base_training_job.py:164-168), so ranks exchange nothing but ONE all-reduce(sum) per
+ *     step over the flat [gradient sums | loss_sum | count] buffer.  These entry points put that collective on the stream
+ *     the step's kernels run on (between hmp_net_step_fwd_bwd and hmp_net_step_adam): RCCL over xGMI, one process per GPU.
+ *     Rendezvous: rank 0 calls hmp_comm_unique_id and hands the 128 bytes to the other ranks by any channel the host has
+ *     (torch.distributed broadcast, a file, MPI); every rank then calls hmp_comm_create with the device it owns current.
+ *     RCCL is resolved at the first call (dlopen): HMP_E_UNSUPPORTED when the machine has none.
+ * ------------------------------------------------------------------------------------------- */
+#define HMP_COMM_ID_BYTES 128
+typedef struct hmp_comm hmp_comm; /* opaque */
+int hmp_comm_unique_id(void* id128);
+int hmp_comm_create(const void* id128, int32_t rank, int32_t world, hmp_comm** out);
+void hmp_comm_destroy(hmp_comm* comm);
+int hmp_comm_allreduce_sum_f32(hmp_comm* comm, float* d_buf, int64_t n, void* stream);
+int hmp_comm_broadcast_f32(hmp_comm* comm, float* d_buf, int64_t n, int32_t root, void* stream);
 
 #ifdef __cplusplus
 }
