@@ -734,7 +734,15 @@ const float* h_ptr(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? 
 int h_ld(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.ldx[t] : n->ld[l][t]; }
 
 // bf16 compute mode: only the throughput-bound regime (>= 1024 64x64 tiles in the call) leaves the exact fp32 kernel
+// HMP_BF16_ALL=1 (tests): every GEMM call of a bf16-mode net takes the bf16 kernel whatever its size, so that a graph the
+// float64 oracle can hold (4 x 10^4 objects) runs exactly the decisions of the 10^6-object regime (BASELINE config 5)
+inline bool bf16_all() {
+  const char* v = getenv("HMP_BF16_ALL");
+  return v && v[0] == '1';
+}
+
 bool gemm_takes_bf16(const std::vector<GemmProblem>& ps, bool allow_bf16) {
+  if (allow_bf16 && bf16_all()) return true;
   int64_t tiles64 = 0;
   double work = 0.0;
   for (const GemmProblem& p : ps) {
@@ -996,7 +1004,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         if (hb) {
           double work = 0.0;
           for (int s = 0; s < n->T; ++s) work += (double)b->n_nodes[s] * n->lay[l + 1].ncols[s] * n->dim[l + 1][s];
-          hb = work >= 1e9;  // gemm_takes_bf16's work criterion
+          hb = work >= 1e9 || bf16_all();  // gemm_takes_bf16's work criterion
         }
         const char* hv = getenv("HMP_H16");  // 0: keep fp32 activations (tests)
         if (hv && hv[0] == '0') hb = false;
@@ -1443,6 +1451,20 @@ extern "C" int hmp_net_aux_output(hmp_net* n, const float** d_out, int32_t* ld_o
   *d_out = n->H[n->L][at];
   *ld_out = n->ld[n->L][at];
   *n_rows = n->batch.n_nodes[at];
+  return HMP_OK;
+}
+
+extern "C" int hmp_net_hidden(hmp_net* n, int32_t layer, int32_t node_type, const void** d_h, int32_t* ld, int32_t* n_rows,
+                              int32_t* width, int32_t* is_bf16) {
+  HMP_CHECK_ARG(n && d_h && ld && n_rows && width && is_bf16, "hmp_net_hidden: null argument");
+  HMP_CHECK_ARG(n->have_fwd, "hmp_net_hidden: needs a forward");
+  HMP_CHECK_ARG(layer >= 1 && layer <= n->L && node_type >= 0 && node_type < n->T && n->H[layer][node_type] != nullptr,
+                "hmp_net_hidden: layer %d / node type %d has no stored output", layer, node_type);
+  *d_h = n->H[layer][node_type];
+  *ld = n->ld[layer][node_type];
+  *n_rows = n->batch.n_nodes[node_type];
+  *width = n->dim[layer][node_type];
+  *is_bf16 = n->h16[layer][node_type] ? 1 : 0;
   return HMP_OK;
 }
 

@@ -126,6 +126,7 @@ SIGNATURES = {
     "hmp_net_step_fwd_bwd": (C.c_int, [_VP, C.POINTER(Batch), _VP, _VP, C.POINTER(TrainArgs), _VP]),
     "hmp_net_step_adam": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(TrainArgs), _VP]),
     "hmp_net_step_fused": (C.c_int, [_VP, C.POINTER(Batch), _VP, _VP, _VP, _VP, C.POINTER(TrainArgs), _VP]),
+    "hmp_net_hidden": (C.c_int, [_VP, _I32, _I32, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "hmp_net_read_state": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32), _VP]),
     "hmp_graph_begin": (C.c_int, [_VP]),
     "hmp_graph_end": (C.c_int, [_VP, C.POINTER(_VP)]),

@@ -404,6 +404,17 @@ class NativeNet:
                                                    grads.data_ptr(), None, _lib.stream_ptr()))
         return grads
 
+    def hidden(self, layer: int, node_type: str) -> torch.Tensor:
+        """Copy (fp32) of the stored output of ``layer`` (1-based) for ``node_type`` from the last forward (``hmp_net_hidden``;
+        diagnosis / tests).  Dropped elements are ``-0.0``."""
+        p, ld, rows, width, b16 = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._lib.hmp_net_hidden(self._handle, int(layer), self.node_types.index(node_type), C.byref(p), C.byref(ld),
+                                            C.byref(rows), C.byref(width), C.byref(b16)))
+        esz = 2 if b16.value else 4
+        off = p.value - self._ws.data_ptr()
+        raw = self._ws[off:off + rows.value * ld.value * esz].view(torch.bfloat16 if b16.value else torch.float32)
+        return raw.view(rows.value, ld.value)[:, :width.value].to(torch.float32).clone()
+
     def read_state(self) -> Tuple[int, int]:
         step, status = C.c_int32(), C.c_int32()
         _lib.check(self._lib.hmp_net_read_state(self._handle, C.byref(step), C.byref(status), _lib.stream_ptr()))

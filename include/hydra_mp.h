@@ -270,6 +270,11 @@ int hmp_net_step_adam(hmp_net* net, float* d_params, const float* d_grads, float
  * gradient un-pack kernel where the network allows it (SAGE stacks); the result equals A followed by B. */
 int hmp_net_step_fused(hmp_net* net, const hmp_batch* batch, float* d_params, float* d_grads, float* d_m, float* d_v,
                        const hmp_train_args* args, void* stream);
+/* diagnosis / tests: where the last forward left the output of layer `layer` (1 .. n_layers) for `node_type`: rows [n_rows, width]
+ * at pitch *ld elements, fp32 or (*is_bf16) bfloat16.  A dropped element (training-mode dropout) is stored as -0: its sign bit
+ * is the keep-mask the backward reads.  Valid until the next forward / step / workspace re-bind. */
+int hmp_net_hidden(hmp_net* net, int32_t layer, int32_t node_type, const void** d_h, int32_t* ld, int32_t* n_rows,
+                   int32_t* width, int32_t* is_bf16);
 /* compute mode of the dense projections: 0 (default) exact fp32 MFMA everywhere; 1 = GEMM calls in the throughput-bound regime
  * (>= 1024 64x64 output tiles: BASELINE config 5) round their fp32 operands to bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation.  Storage stays fp32.  Not within the 1e-5 parity bar: an explicit precision choice of the caller. */

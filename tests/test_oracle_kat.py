@@ -226,3 +226,43 @@ def test_gcn_gin_gradcheck(block):
         return net(type("D", (), dict(x=xx, edge_index=ei, room_mask=mask)))
 
     assert torch.autograd.gradcheck(f, (x,), atol=1e-6)
+
+
+def test_bf16_contract_restatement_equals_pyg_restatement_without_rounding():
+    """oracle/bf16_emul.py follows the engine's project-then-aggregate algebra so that it can round where the engine rounds.
+    With every rounding switched off it must be the SAME function as the PyG restatement (aggregate-then-project): logits,
+    loss and every gradient agree to float64 round-off, dead last-layer convs get no gradient in both."""
+    import copy
+
+    from hydra_gnn_amd import workloads
+    from oracle import bf16_emul, models as omodels
+
+    torch.manual_seed(3)
+    kw = dict(input_dim_dict={"objects": 32, "rooms": 32}, output_dim=26, conv_block="GraphSAGE", hidden_dim=32, num_layers=3, dropout=0.0)
+    ora = omodels.HeterogeneousNetwork(**kw)
+    g = workloads.big_hetero_graph(n_obj=300, n_rooms=12, deg=5, feat_dim=32, seed=4)
+    o64 = copy.deepcopy(ora).double()
+    b64 = g.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    y = g["rooms"].y
+    pred = o64(b64)
+    loss = o64.loss(pred, y, y != 25)
+    loss.backward()
+    logits, l2, grads = bf16_emul.sage_hetero_bf16(ora, g, dtype=torch.float64, rounding=False)
+    # not 1e-12: the restatement sums the root weights / biases of a destination type in fp32 first (as the engine's pack does)
+    torch.testing.assert_close(logits, pred.detach(), atol=5e-7, rtol=1e-6)
+    torch.testing.assert_close(l2, loss.detach(), atol=5e-7, rtol=1e-6)
+    ref = dict(o64.named_parameters())
+    n_checked = 0
+    for name, p in ref.items():
+        if p.grad is None:
+            assert name not in grads or grads[name] is None, name
+            continue
+        torch.testing.assert_close(grads[name].double(), p.grad, atol=5e-7, rtol=1e-6, msg=lambda m: f"{name}: {m}")
+        n_checked += 1
+    assert n_checked >= 20
+    # and the rounding really rounds: bf16 contract differs from the exact function by about 2^-9 relative
+    lr, _, _ = bf16_emul.sage_hetero_bf16(ora, g, dtype=torch.float64, rounding=True)
+    rel = float((lr - logits).abs().max() / logits.abs().max())
+    assert 1e-4 < rel < 5e-2, rel
