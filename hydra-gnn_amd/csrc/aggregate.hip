@@ -9,6 +9,8 @@
 // No atomics anywhere: the backward pass gathers over the transposed lists (CSC) instead of scattering.
 //
 // HBM/L2 traffic per row: deg * F * 4 bytes of source rows + 4*deg + 8 bytes of indices + F*4 out.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace hmp {
@@ -28,7 +30,13 @@ struct Acc<4> {
   __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
   __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
   __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
-  __device__ __forceinline__ void add_div(const Acc& o, float d) { v.x += o.v.x / d; v.y += o.v.y / d; v.z += o.v.z / d; v.w += o.v.w / d; }
+  // mean of a segment: sum * (1 / deg), the reciprocal computed ONCE (an IEEE division; wave-uniform where the row is) and applied
+  // by explicit fused multiply-adds -- the same form in every kernel, so all of them stay bit-identical to each other (the
+  // backward pass multiplies by the same reciprocal: hmp plan's degf).  x / deg per element cost 4 divisions per lane and edge type.
+  __device__ __forceinline__ void add_div(const Acc& o, float d) {
+    const float r = 1.0f / d;
+    v.x = fmaf(o.v.x, r, v.x); v.y = fmaf(o.v.y, r, v.y); v.z = fmaf(o.v.z, r, v.z); v.w = fmaf(o.v.w, r, v.w);
+  }
   __device__ __forceinline__ void add_mul(const Acc& o, float r) { v.x += o.v.x * r; v.y += o.v.y * r; v.z += o.v.z * r; v.w += o.v.w * r; }
   __device__ __forceinline__ void div(float d) { v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
   __device__ __forceinline__ float& at(int i) { return (&v.x)[i]; }
@@ -40,7 +48,7 @@ struct Acc<1> {
   __device__ __forceinline__ void load(const float* p) { v = *p; }
   __device__ __forceinline__ void store(float* p) const { *p = v; }
   __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
-  __device__ __forceinline__ void add_div(const Acc& o, float d) { v += o.v / d; }
+  __device__ __forceinline__ void add_div(const Acc& o, float d) { v = fmaf(o.v, 1.0f / d, v); }
   __device__ __forceinline__ void add_mul(const Acc& o, float r) { v += o.v * r; }
   __device__ __forceinline__ void div(float d) { v /= d; }
   __device__ __forceinline__ float& at(int) { return v; }
@@ -370,7 +378,7 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
       if (D.act == HMP_ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (D.act == HMP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
       // a dropped element is stored as -0.0f (a kept one that happens to be zero as +0.0f): numerically both are 0 for
-      // every consumer, and the backward pass reads the keep bit off the sign instead of regenerating Philox draws
+      // every consumer, and the backward pass reads the keep bit off the sign instead of regenerating the draws
       if (D.drop_on) v = keep[i] ? (v * D.drop.scale + 0.0f) : -0.0f;  // "+ 0.0f": a kept -0.0 becomes +0.0
       tot[q].at(i) = v;
     }
@@ -891,6 +899,509 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   KT(10);
 }
 
+// ----- LDS sliding-window aggregation for the 10^6-row regime (bf16 rows of 256 elements = 512 bytes) ------------------------
+// Scene graphs are local: an object's neighbours are objects of the same room, and a graph builder numbers the objects of a
+// room consecutively, so the source rows that a run of consecutive destination rows gathers lie in a narrow index window
+// around the run (config 5: 90 % of a row's 16 neighbours inside its room's ~100 rows).  The one-wave-per-row kernels above
+// fetch every neighbour row through L2 -> L1 -> registers once per EDGE (17 x 512 B per row, 9 GB per launch at 10^6 rows) and
+// -- measured -- are bound by LATENCY x rows in flight, not by bytes: a row is a chain of 4 dependent round trips (extent ->
+// neighbour ids -> rows -> more rows) of ~2 us each with ~24 rows in flight per CU.
+//
+// Here ONE persistent 1024-thread workgroup per CU walks a contiguous range of destination rows in chunks of WR = 64 and keeps
+// a RING of WRING = 256 source rows in LDS (128 KiB): the chunk's own rows plus WM = 64 rows of margin either side.  Moving on
+// one chunk brings exactly WR new rows in -- into the ring slots the new window no longer covers -- so every source row enters
+// the CU ONCE per launch, with coalesced 16-byte loads issued one chunk ahead (they land while the current chunk computes).
+// The chunk's CSR slice (row extents and neighbour ids of every incoming edge type: one contiguous range per type) is staged
+// in LDS the same way, two / one chunks ahead.  A row then costs LDS reads only, except for the neighbours outside the window
+// (the 10 % global edges; the other edge types, e.g. the room row of an object).  Lane u of the wave computes edge u's source
+// address -- a slot of the LDS ring or a row in global memory -- as ONE generic (flat) pointer, so the row loads of a batch
+// of 8 edges are branch-free flat loads whatever the mix.  Sums run in edge order through one accumulator per edge type,
+// whatever the source of a row: bit-identical to the kernels above.  Only the edge type whose source index space IS the destination's (objects -> objects) is windowed -- for bipartite
+// types every source row is used once and staging buys nothing.
+constexpr int WIN_THREADS = 1024;
+constexpr int WIN_WAVES = WIN_THREADS / 64;
+constexpr int WIN_ROW_BYTES = 512;  // 256 bf16
+constexpr int WR = 64;              // destination rows per chunk
+constexpr int WM = 64;              // margin rows either side
+constexpr int WRING = 256;          // ring rows = WR + 2 WM + WR (power of two: slot = row & 255)
+constexpr int WG = WR / WIN_WAVES;  // rows per wave and chunk (4)
+constexpr int WIDCAP = 3072;        // neighbour ids per chunk staged in LDS (all incoming edge types; avg 64 x 17 = 1088)
+constexpr int WRP = WR + 1;
+constexpr int WIN_LDS_RING = (WRING + 1) * WIN_ROW_BYTES;  // + one all-zero row (slot WRING): what an out-of-window edge reads from LDS
+constexpr int WIN_LDS_IDS = 2 * WIDCAP * 4;
+constexpr int WIN_LDS_RP = 3 * AGG_MAX_IN * WRP * 4;
+constexpr int WIN_LDS_DEG = WRING * 4;  // backward: reciprocal in-degrees of the ring rows
+constexpr int WIN_LDS_FWD = WIN_LDS_RING + WIN_LDS_IDS + WIN_LDS_RP;
+constexpr int WIN_LDS_BWD = WIN_LDS_FWD + WIN_LDS_DEG;
+static_assert(WIN_LDS_BWD <= 160 * 1024, "LDS budget");
+constexpr unsigned WIN_SKIP_OFF = 0xFFFFF000u;  // buffer offset beyond any record: the load returns 0 without touching memory
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// raw buffer over [base, base + bytes): an out-of-range offset reads as zero (no memory access) -- lets a batch of edges issue BOTH
+// an LDS read and a global read per edge without a branch: the one that does not apply is aimed at the zero row / out of range
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+static_assert(AGG_MAX_IN == 6 && WG == 4, "sel_q / sel_root are written for 6 / 4 entries");
+struct WinFwd {
+  AggDst d;  // ONE destination entry, win_in >= 0
+  int mean;
+  int n_chunks, chunks_per_block;
+};
+struct WinBwd {
+  TAggSrc s;  // ONE source entry, win_out >= 0
+  int mean, dzb16;
+  int n_chunks, chunks_per_block;
+};
+
+__device__ __forceinline__ void widen_bf16x4(Acc<4>& a, const uint2 b) {
+  a.v = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u), __uint_as_float(b.y << 16),
+                    __uint_as_float(b.y & 0xffff0000u));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint2 sel_root(const uint2 (&s)[WG], int g) {  // g wave-uniform: a scalar branch tree
+  switch (g) {
+    case 0: return s[0];
+    case 1: return s[1];
+    case 2: return s[2];
+    default: return s[3];
+  }
+}
+__device__ __forceinline__ int sel_st(const int (&s)[AGG_MAX_IN + 1], int q) {  // q wave-uniform
+  switch (q) {
+    case 0: return s[0];
+    case 1: return s[1];
+    case 2: return s[2];
+    case 3: return s[3];
+    case 4: return s[4];
+    case 5: return s[5];
+    default: return s[6];
+  }
+}
+__device__ __forceinline__ int sel_q(const int (&s)[AGG_MAX_IN], int q) {  // q wave-uniform
+  switch (q) {
+    case 0: return s[0];
+    case 1: return s[1];
+    case 2: return s[2];
+    case 3: return s[3];
+    case 4: return s[4];
+    default: return s[5];
+  }
+}
+// Shared chunk pipeline of the forward and the transposed kernel.  `Side` supplies, per edge type q of the entry: the extent
+// array (rowptr), the id array (col), the gathered matrix (base pointer as bf16 elements, column offset, pitch) and, for the
+// transposed side, the per-row weights.
+struct WinStage {  // registers holding what phase A requested for the chunks ahead
+  uint4 rows[(WR * 32) / WIN_THREADS];          // 2: the WR new ring rows of chunk c + 1
+  int ids[(WIDCAP + WIN_THREADS - 1) / WIN_THREADS];  // 3: ids of chunk c + 1
+  int rp;                                        // extents of chunk c + 2
+  float deg;                                     // backward: reciprocal degrees of the new ring rows
+};
+
+template <class E>  // E: AggDst (forward: in[].rowptr / col) or TAggSrc (transposed: out[].t_rowptr / t_col)
+struct WinTopo;
+template <>
+struct WinTopo<AggDst> {
+  static __device__ __forceinline__ int n(const AggDst& D) { return D.n_in; }
+  static __device__ __forceinline__ const int* rowptr(const AggDst& D, int q) { return D.in[q].rowptr; }
+  static __device__ __forceinline__ const int* col(const AggDst& D, int q) { return D.in[q].col; }
+  static __device__ __forceinline__ int rows(const AggDst& D) { return D.n_rows; }
+};
+template <>
+struct WinTopo<TAggSrc> {
+  static __device__ __forceinline__ int n(const TAggSrc& S) { return S.n_out; }
+  static __device__ __forceinline__ const int* rowptr(const TAggSrc& S, int q) { return S.out[q].t_rowptr; }
+  static __device__ __forceinline__ const int* col(const TAggSrc& S, int q) { return S.out[q].t_col; }
+  static __device__ __forceinline__ int rows(const TAggSrc& S) { return S.n_rows; }
+};
+
+// extents of chunk `ch` -> register (thread t < n * WRP owns element t)
+template <class E>
+__device__ __forceinline__ int win_load_rp(const E& X, int ch, int n_chunks) {
+  const int t = threadIdx.x, nq = WinTopo<E>::n(X);
+  if (ch >= n_chunks || t >= nq * WRP) return 0;
+  const int q = t / WRP, i = t - q * WRP;
+  const int r = min(ch * WR + i, WinTopo<E>::rows(X));
+  return WinTopo<E>::rowptr(X, q)[r];
+}
+// ids of chunk `ch` (extents already in LDS buffer rp) -> registers; returns the id total of the chunk through *total
+template <class E>
+__device__ __forceinline__ void win_load_ids(const E& X, const int* rp, bool live, int (&ids)[(WIDCAP + WIN_THREADS - 1) / WIN_THREADS]) {
+  const int nq = WinTopo<E>::n(X);
+  int start[AGG_MAX_IN + 1], eb[AGG_MAX_IN];
+  start[0] = 0;
+#pragma unroll
+  for (int q = 0; q < AGG_MAX_IN; ++q) {
+    eb[q] = 0;
+    int len = 0;
+    if (live && q < nq) { eb[q] = rp[q * WRP]; len = rp[q * WRP + WR] - eb[q]; }
+    start[q + 1] = start[q] + len;
+  }
+  const bool fits = start[AGG_MAX_IN] <= WIDCAP;
+#pragma unroll
+  for (int it = 0; it < (WIDCAP + WIN_THREADS - 1) / WIN_THREADS; ++it) {
+    const int p = (int)threadIdx.x + it * WIN_THREADS;
+    ids[it] = 0;
+    if (fits && p < start[AGG_MAX_IN]) {
+      const int* cq = WinTopo<E>::col(X, 0);
+      int ebq = eb[0], stq = 0;
+#pragma unroll
+      for (int t = 1; t < AGG_MAX_IN; ++t)
+        if (t < nq && p >= start[t]) { cq = WinTopo<E>::col(X, t); ebq = eb[t]; stq = start[t]; }
+      ids[it] = cq[ebq + (p - stq)];
+    }
+  }
+}
+// per-chunk view of the staged CSR slice: id offset of every edge type inside the id buffer; false: the chunk did not fit
+__device__ __forceinline__ bool win_offsets(const int* rp, int nq, int (&off)[AGG_MAX_IN], int (&eb)[AGG_MAX_IN]) {
+  int acc = 0;
+#pragma unroll
+  for (int q = 0; q < AGG_MAX_IN; ++q) {
+    off[q] = acc;
+    eb[q] = 0;
+    if (q < nq) { eb[q] = rp[q * WRP]; acc += rp[q * WRP + WR] - eb[q]; }
+  }
+  return acc <= WIDCAP;
+}
+
+template <bool HB>
+__global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+  unsigned char* ring = wlds;
+  int* idbuf = reinterpret_cast<int*>(wlds + WIN_LDS_RING);                 // [2][WIDCAP]
+  int* rpbuf = reinterpret_cast<int*>(wlds + WIN_LDS_RING + WIN_LDS_IDS);   // [3][AGG_MAX_IN][WRP]
+  const AggDst& D = a.d;
+  const int n_rows = D.n_rows, nq = D.n_in;
+  const int c_begin = (int)blockIdx.x * a.chunks_per_block;
+  const int c_end = min(c_begin + a.chunks_per_block, a.n_chunks);
+  if (c_begin >= c_end) return;  // block-uniform
+  const int wave = uni((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const AggIn& IW = D.in[D.win_in];
+  const uint16_t* zwin = reinterpret_cast<const uint16_t*>(IW.z) + IW.coff;
+  const int c0 = lane * 4;
+  DropCfg dcfg = D.drop;
+  if (D.drop_on) dcfg = drop_resolve(D.drop);
+  Acc<4> biasv;  // the lane's 4 bias columns: the same for every row
+  biasv.zero();
+  if (D.bias) biasv.load(D.bias + c0);
+
+  // ---- prologue: extents of chunks c_begin, c_begin + 1; ids of c_begin; the first window -------------------------------
+  {
+    const int r0 = win_load_rp(D, c_begin, a.n_chunks), r1 = win_load_rp(D, c_begin + 1, a.n_chunks);
+    if ((int)threadIdx.x < nq * WRP) {
+      rpbuf[(c_begin % 3) * AGG_MAX_IN * WRP + threadIdx.x] = r0;
+      rpbuf[((c_begin + 1) % 3) * AGG_MAX_IN * WRP + threadIdx.x] = r1;
+    }
+    if ((int)threadIdx.x < 32) *reinterpret_cast<uint4*>(ring + (size_t)WRING * WIN_ROW_BYTES + threadIdx.x * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // rows [lo, hi) of the first window (everything the ring will hold for chunk c_begin)
+    const int lo = max(c_begin * WR - WM, 0), hi = min(c_begin * WR + WR + WM, n_rows);
+    for (int p = threadIdx.x; p < (hi - lo) * 32; p += WIN_THREADS) {
+      const int r = lo + (p >> 5), piece = p & 31;
+      const uint4 v = *reinterpret_cast<const uint4*>(zwin + (int64_t)r * IW.ldz + piece * 8);
+      *reinterpret_cast<uint4*>(ring + (size_t)(r & (WRING - 1)) * WIN_ROW_BYTES + piece * 16) = v;
+    }
+    __syncthreads();
+    int ids[(WIDCAP + WIN_THREADS - 1) / WIN_THREADS];
+    win_load_ids(D, rpbuf + (c_begin % 3) * AGG_MAX_IN * WRP, true, ids);
+#pragma unroll
+    for (int it = 0; it < (WIDCAP + WIN_THREADS - 1) / WIN_THREADS; ++it) {
+      const int p = (int)threadIdx.x + it * WIN_THREADS;
+      if (p < WIDCAP) idbuf[(c_begin & 1) * WIDCAP + p] = ids[it];
+    }
+    __syncthreads();
+  }
+
+  for (int i = 20; i < 31; ++i) KT_ZERO(i);
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int r_c = ch * WR;
+    const int* rp = rpbuf + (ch % 3) * AGG_MAX_IN * WRP;
+    const int* idc = idbuf + (ch & 1) * WIDCAP;
+    [[maybe_unused]] const unsigned long long kt_a = KT_NOW();
+    // ---- phase A: request what the NEXT chunks need (lands while this chunk computes) ------------------------------------
+    WinStage stg;
+    const bool next = ch + 1 < c_end;
+    {
+      const int nlo = r_c + WR + WM;  // new ring rows of chunk ch + 1: [nlo, nlo + WR)
+#pragma unroll
+      for (int it = 0; it < (WR * 32) / WIN_THREADS; ++it) {
+        const int p = (int)threadIdx.x + it * WIN_THREADS;
+        const int r = nlo + (p >> 5), piece = p & 31;
+        stg.rows[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (next && r < n_rows) stg.rows[it] = *reinterpret_cast<const uint4*>(zwin + (int64_t)r * IW.ldz + piece * 8);
+      }
+      win_load_ids(D, rpbuf + ((ch + 1) % 3) * AGG_MAX_IN * WRP, next, stg.ids);
+      stg.rp = (ch + 2 < c_end) ? win_load_rp(D, ch + 2, a.n_chunks) : 0;
+    }
+    KT_ADD(20, kt_a);
+    [[maybe_unused]] const unsigned long long kt_c = KT_NOW();
+    // ---- this chunk ----------------------------------------------------------------------------------------------------------
+    int off[AGG_MAX_IN], eb[AGG_MAX_IN];
+    const bool fits = win_offsets(rp, nq, off, eb);
+    const int wlo = max(r_c - WM, 0), whi = min(r_c + WR + WM, n_rows);  // rows the ring holds now
+    {  // (!fits, block-uniform: a chunk with more ids than the LDS slice holds reads extents / ids from global memory, no window)
+      // phase B: root rows of all WG rows of this wave requested together
+      uint2 root[WG];
+#pragma unroll
+      for (int g = 0; g < WG; ++g) {
+        const int row = r_c + g * WIN_WAVES + wave;
+        root[g] = make_uint2(0u, 0u);
+        if (row < n_rows && D.zroot)
+          root[g] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(D.zroot) + (int64_t)row * D.ldzr + D.roff + c0);
+      }
+      // phase C: sums in edge order, one accumulator per edge type.  The neighbour id of an edge is wave-uniform (readlane), so
+      // its row comes either from the LDS ring (one ds_read_b64 at a scalar-computed slot) or from global memory (scalar base +
+      // lane offset): a scalar branch per edge, no per-lane address arithmetic, 16 loads in flight per batch.
+#pragma unroll 1
+      for (int g = 0; g < WG; ++g) {
+        const int rl = g * WIN_WAVES + wave, row = r_c + rl;
+        if (row >= n_rows) continue;
+        [[maybe_unused]] const unsigned long long kt_r = KT_NOW();
+        Acc<4> tot;
+        tot.zero();
+        if (D.zroot) widen_bf16x4(tot, sel_root(root, g));
+        tot.add(biasv);
+#pragma unroll 1
+        for (int q = 0; q < nq; ++q) {
+          const AggIn& I = D.in[q];
+          const int b = fits ? uni(rp[q * WRP + rl]) : I.rowptr[row], e = fits ? uni(rp[q * WRP + rl + 1]) : I.rowptr[row + 1];
+          if (e == b) continue;
+          const uint16_t* zq = reinterpret_cast<const uint16_t*>(I.z) + I.coff;
+          const int ldq = I.ldz;
+          const __amdgpu_buffer_rsrc_t rs = win_rsrc(zq, (unsigned)I.n_src * (unsigned)(ldq * 2) - (unsigned)(I.coff * 2));
+          const __amdgpu_buffer_rsrc_t rs_null = win_rsrc(zq, 0u);
+          const int offq = fits ? sel_q(off, q) + (b - sel_q(eb, q)) : 0;
+          const bool wq = fits && q == D.win_in;
+          Acc<4> acc;
+          acc.zero();
+          for (int base = 0; base < e - b; base += 64) {
+            const int cnt = min(e - b - base, 64);
+            const int idv = lane < cnt ? (fits ? idc[offq + base + lane] : I.col[b + base + lane]) : 0;
+            // lane u prepares edge u: BOTH sources are read for every edge, branch-free (the compiler drains the memory counters
+            // at every control-flow join; flat loads into LDS run at a fraction of the ds_read rate): the LDS read aims at the
+            // ring slot or at the all-zero row, the buffer read at the global row or -- through a descriptor of zero records --
+            // at nothing (returns 0 without a memory access); the row is their OR.  Per edge that leaves two readlanes, one
+            // address add and two scalar selects: the scalar unit is shared by the CU's four SIMDs and was the bound (measured:
+            // 615 scalar instructions per row with per-edge scalar address arithmetic).
+            const bool inw = lane < cnt && wq && idv >= wlo && idv < whi;
+            const int lov = inw ? (idv & (WRING - 1)) * WIN_ROW_BYTES : WRING * WIN_ROW_BYTES;
+            const int gov = (lane < cnt && !inw) ? idv * (ldq * 2) : 0;
+            const unsigned long long mnull = __ballot(inw || lane >= cnt);  // edges that read nothing from global memory
+            auto batch = [&](int u0, auto nb) {
+              constexpr int NB = decltype(nb)::value;
+              uint2 va[NB];
+              u32x2 vb[NB];
+#pragma unroll
+              for (int t = 0; t < NB; ++t) {
+                const int u = u0 + t;  // < 64: edges past cnt read the zero row / nothing and add +0
+                const int so = __builtin_amdgcn_readlane(lov, u), sg = __builtin_amdgcn_readlane(gov, u);
+                va[t] = *reinterpret_cast<const uint2*>(ring + so + lane * 8);
+                vb[t] = __builtin_amdgcn_raw_buffer_load_b64(((mnull >> u) & 1ull) ? rs_null : rs, lane * 8, sg, 0);
+              }
+#pragma unroll
+              for (int t = 0; t < NB; ++t) {
+                Acc<4> w;
+                widen_bf16x4(w, make_uint2(va[t].x | vb[t][0], va[t].y | vb[t][1]));
+                acc.add(w);
+              }
+            };
+            int u0 = 0;
+            for (; cnt - u0 > 2; u0 += 8) batch(u0, std::integral_constant<int, 8>());
+            if (u0 < cnt) batch(u0, std::integral_constant<int, 2>());
+          }
+          tot.add_div(acc, a.mean ? (float)(e - b) : 1.f);
+        }
+        KT_ADD(29, kt_r);
+        bool keep[4] = {true, true, true, true};
+        if (D.drop_on) drop_keep4(dcfg, (uint32_t)row * (uint32_t)(D.ldo >> 2) + (uint32_t)(c0 >> 2), keep);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // as agg_row's epilogue
+          float v = tot.at(i);
+          if (D.act == HMP_ACT_RELU) v = v > 0.f ? v : 0.f;
+          else if (D.act == HMP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+          if (D.drop_on) v = keep[i] ? (v * D.drop.scale + 0.0f) : -0.0f;
+          tot.at(i) = v;
+        }
+        store_z<HB>(tot, D.out, (int64_t)row * D.ldo + c0);
+        KT_ADD(30, kt_r);
+      }
+    }
+    KT_ADD(21, kt_c);
+    [[maybe_unused]] const unsigned long long kt_d = KT_NOW();
+    // ---- phase D: what phase A requested goes to LDS (ring slots / buffers this chunk did not read) -------------------------
+    if (next) {
+      const int nlo = r_c + WR + WM;
+#pragma unroll
+      for (int it = 0; it < (WR * 32) / WIN_THREADS; ++it) {
+        const int p = (int)threadIdx.x + it * WIN_THREADS;
+        const int r = nlo + (p >> 5), piece = p & 31;
+        if (r < n_rows) *reinterpret_cast<uint4*>(ring + (size_t)(r & (WRING - 1)) * WIN_ROW_BYTES + piece * 16) = stg.rows[it];
+      }
+#pragma unroll
+      for (int it = 0; it < (WIDCAP + WIN_THREADS - 1) / WIN_THREADS; ++it) {
+        const int p = (int)threadIdx.x + it * WIN_THREADS;
+        if (p < WIDCAP) idbuf[((ch + 1) & 1) * WIDCAP + p] = stg.ids[it];
+      }
+      if (ch + 2 < c_end && (int)threadIdx.x < nq * WRP) rpbuf[((ch + 2) % 3) * AGG_MAX_IN * WRP + threadIdx.x] = stg.rp;
+    }
+    KT_ADD(22, kt_d);
+    [[maybe_unused]] const unsigned long long kt_b = KT_NOW();
+    __syncthreads();
+    KT_ADD(23, kt_b);
+    KT_ADD(24, kt_a);
+  }
+}
+
+// transposed counterpart: source rows in chunks, ring over the gradient rows G of the destination type (same index space) and
+// their reciprocal in-degrees; one accumulator and one output segment per outgoing edge type
+template <bool DZB>
+__global__ __launch_bounds__(WIN_THREADS) void agg_bwd_win_kernel(const WinBwd a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+  unsigned char* ring = wlds;
+  int* idbuf = reinterpret_cast<int*>(wlds + WIN_LDS_RING);
+  int* rpbuf = reinterpret_cast<int*>(wlds + WIN_LDS_RING + WIN_LDS_IDS);
+  float* wdeg = reinterpret_cast<float*>(wlds + WIN_LDS_FWD);
+  const TAggSrc& S = a.s;
+  const int n_rows = S.n_rows, nq = S.n_out;
+  const int c_begin = (int)blockIdx.x * a.chunks_per_block;
+  const int c_end = min(c_begin + a.chunks_per_block, a.n_chunks);
+  if (c_begin >= c_end) return;
+  const int wave = uni((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const TAggOut& OW = S.out[S.win_out];
+  const uint16_t* gwin = reinterpret_cast<const uint16_t*>(OW.g);
+  const bool wdg = a.mean && OW.degf != nullptr;
+  const int c0 = lane * 4;
+  {
+    const int r0 = win_load_rp(S, c_begin, a.n_chunks), r1 = win_load_rp(S, c_begin + 1, a.n_chunks);
+    if ((int)threadIdx.x < nq * WRP) {
+      rpbuf[(c_begin % 3) * AGG_MAX_IN * WRP + threadIdx.x] = r0;
+      rpbuf[((c_begin + 1) % 3) * AGG_MAX_IN * WRP + threadIdx.x] = r1;
+    }
+    if ((int)threadIdx.x < 32) *reinterpret_cast<uint4*>(ring + (size_t)WRING * WIN_ROW_BYTES + threadIdx.x * 16) = make_uint4(0u, 0u, 0u, 0u);
+    const int lo = max(c_begin * WR - WM, 0), hi = min(c_begin * WR + WR + WM, n_rows);
+    for (int p = threadIdx.x; p < (hi - lo) * 32; p += WIN_THREADS) {
+      const int r = lo + (p >> 5), piece = p & 31;
+      const uint4 v = *reinterpret_cast<const uint4*>(gwin + (int64_t)r * OW.ldg + piece * 8);
+      *reinterpret_cast<uint4*>(ring + (size_t)(r & (WRING - 1)) * WIN_ROW_BYTES + piece * 16) = v;
+    }
+    if (wdg && (int)threadIdx.x < hi - lo) wdeg[(lo + threadIdx.x) & (WRING - 1)] = OW.degf[lo + threadIdx.x];
+    __syncthreads();
+    int ids[(WIDCAP + WIN_THREADS - 1) / WIN_THREADS];
+    win_load_ids(S, rpbuf + (c_begin % 3) * AGG_MAX_IN * WRP, true, ids);
+#pragma unroll
+    for (int it = 0; it < (WIDCAP + WIN_THREADS - 1) / WIN_THREADS; ++it) {
+      const int p = (int)threadIdx.x + it * WIN_THREADS;
+      if (p < WIDCAP) idbuf[(c_begin & 1) * WIDCAP + p] = ids[it];
+    }
+    __syncthreads();
+  }
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int r_c = ch * WR;
+    const int* rp = rpbuf + (ch % 3) * AGG_MAX_IN * WRP;
+    const int* idc = idbuf + (ch & 1) * WIDCAP;
+    WinStage stg;
+    const bool next = ch + 1 < c_end;
+    {
+      const int nlo = r_c + WR + WM;
+#pragma unroll
+      for (int it = 0; it < (WR * 32) / WIN_THREADS; ++it) {
+        const int p = (int)threadIdx.x + it * WIN_THREADS;
+        const int r = nlo + (p >> 5), piece = p & 31;
+        stg.rows[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (next && r < n_rows) stg.rows[it] = *reinterpret_cast<const uint4*>(gwin + (int64_t)r * OW.ldg + piece * 8);
+      }
+      stg.deg = 0.f;
+      if (next && wdg && (int)threadIdx.x < WR && nlo + (int)threadIdx.x < n_rows) stg.deg = OW.degf[nlo + threadIdx.x];
+      win_load_ids(S, rpbuf + ((ch + 1) % 3) * AGG_MAX_IN * WRP, next, stg.ids);
+      stg.rp = (ch + 2 < c_end) ? win_load_rp(S, ch + 2, a.n_chunks) : 0;
+    }
+    int off[AGG_MAX_IN], eb[AGG_MAX_IN];
+    const bool fits = win_offsets(rp, nq, off, eb);
+    const int wlo = max(r_c - WM, 0), whi = min(r_c + WR + WM, n_rows);
+    // phase C (see agg_fwd_win_kernel): one accumulator and one output segment per outgoing edge type
+#pragma unroll 1
+    for (int g = 0; g < WG; ++g) {
+      const int rl = g * WIN_WAVES + wave, row = r_c + rl;
+      if (row >= n_rows) continue;
+#pragma unroll 1
+      for (int q = 0; q < nq; ++q) {
+        const TAggOut& O = S.out[q];
+        const int b = fits ? uni(rp[q * WRP + rl]) : O.t_rowptr[row], e = fits ? uni(rp[q * WRP + rl + 1]) : O.t_rowptr[row + 1];
+        const bool cin = c0 < O.F;
+        const int cc = cin ? c0 : 0;
+        const bool dg = a.mean && O.degf != nullptr;
+        const uint16_t* gq = reinterpret_cast<const uint16_t*>(O.g);
+        const int ldq = O.ldg;
+        const __amdgpu_buffer_rsrc_t rs = win_rsrc(gq, (unsigned)O.n_dst * (unsigned)(ldq * 2));
+        const __amdgpu_buffer_rsrc_t rs_null = win_rsrc(gq, 0u);
+        const int offq = fits ? sel_q(off, q) + (b - sel_q(eb, q)) : 0;
+        const bool wq = fits && q == S.win_out;
+        Acc<4> acc;
+        acc.zero();
+        for (int base = 0; base < e - b; base += 64) {
+          const int cnt = min(e - b - base, 64);
+          const int idv = lane < cnt ? (fits ? idc[offq + base + lane] : O.t_col[b + base + lane]) : 0;
+          const bool inw = wq && idv >= wlo && idv < whi;
+          // the edge's weight 1 / deg(dst): lane u fetches edge u's (from the ring's table or from global memory)
+          float dv = 1.f;
+          if (a.mean && lane < cnt) {
+            if (dg) dv = inw ? wdeg[idv & (WRING - 1)] : O.degf[idv];
+            else { const int g0 = O.rowptr[idv + 1] - O.rowptr[idv]; dv = 1.f / (float)(g0 > 1 ? g0 : 1); }
+          }
+          const int dvi = __float_as_int(dv);
+          const bool inl = lane < cnt && inw;
+          const int lov = inl ? (idv & (WRING - 1)) * WIN_ROW_BYTES : WRING * WIN_ROW_BYTES;  // see agg_fwd_win_kernel
+          const int gov = (lane < cnt && !inw) ? idv * (ldq * 2) : 0;
+          const unsigned long long mnull = __ballot(inl || lane >= cnt);
+          auto batch = [&](int u0, auto nb) {
+            constexpr int NB = decltype(nb)::value;
+            uint2 va[NB];
+            u32x2 vb[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+              const int u = u0 + t;
+              const int so = __builtin_amdgcn_readlane(lov, u), sg = __builtin_amdgcn_readlane(gov, u);
+              va[t] = *reinterpret_cast<const uint2*>(ring + so + lane * 8);
+              vb[t] = __builtin_amdgcn_raw_buffer_load_b64(((mnull >> u) & 1ull) ? rs_null : rs, cc * 2, sg, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+              Acc<4> w;
+              widen_bf16x4(w, make_uint2(va[t].x | vb[t][0], va[t].y | vb[t][1]));
+              if (a.mean) acc.add_mul(w, __int_as_float(__builtin_amdgcn_readlane(dvi, u0 + t))); else acc.add(w);
+            }
+          };
+          int u0 = 0;
+          for (; cnt - u0 > 2; u0 += 8) batch(u0, std::integral_constant<int, 8>());
+          if (u0 < cnt) batch(u0, std::integral_constant<int, 2>());
+        }
+        if (cin) store_z<DZB>(acc, S.dz, (int64_t)row * S.lddz + O.coff + c0);
+      }
+      if (S.groot && c0 < S.Froot) {
+        Acc<4> v;
+        load_z<true>(v, S.groot, (int64_t)row * S.ldgr + c0);
+        store_z<DZB>(v, S.dz, (int64_t)row * S.lddz + S.roff + c0);
+      }
+    }
+    if (next) {
+      const int nlo = r_c + WR + WM;
+#pragma unroll
+      for (int it = 0; it < (WR * 32) / WIN_THREADS; ++it) {
+        const int p = (int)threadIdx.x + it * WIN_THREADS;
+        const int r = nlo + (p >> 5), piece = p & 31;
+        if (r < n_rows) *reinterpret_cast<uint4*>(ring + (size_t)(r & (WRING - 1)) * WIN_ROW_BYTES + piece * 16) = stg.rows[it];
+      }
+      if (wdg && (int)threadIdx.x < WR && nlo + (int)threadIdx.x < n_rows) wdeg[(nlo + threadIdx.x) & (WRING - 1)] = stg.deg;
+#pragma unroll
+      for (int it = 0; it < (WIDCAP + WIN_THREADS - 1) / WIN_THREADS; ++it) {
+        const int p = (int)threadIdx.x + it * WIN_THREADS;
+        if (p < WIDCAP) idbuf[((ch + 1) & 1) * WIDCAP + p] = stg.ids[it];
+      }
+      if (ch + 2 < c_end && (int)threadIdx.x < nq * WRP) rpbuf[((ch + 2) % 3) * AGG_MAX_IN * WRP + threadIdx.x] = stg.rp;
+    }
+    __syncthreads();
+  }
+}
+
 // ----- dispatch ---------------------------------------------------------------------------------------
 // lanes needed = ceil(F / VEC); GS = next pow2 in [8, 64]; NV = ceil(lanes / GS) <= 4
 // Measured at config 5 (10^6 rows of 256 floats, rocprofv3 --pmc): 152 M L2 requests per forward launch (= the 128-byte lines
@@ -927,6 +1438,44 @@ static bool agg_xcd_enabled() {  // HMP_AGG_XCD=0: plain block order (tests comp
   return !(v && v[0] == '0');
 }
 
+// HMP_AGG_WIN=0 turns the LDS sliding-window kernels off (tests compare both forms bit for bit)
+static bool agg_win_enabled() {
+  const char* v = getenv("HMP_AGG_WIN");
+  return !(v && v[0] == '0');
+}
+constexpr int AGG_WIN_MIN_ROWS = 16384;  // below: a persistent grid would leave CUs idle, the plain kernels do as well
+static int agg_win_grid(int n_chunks, int& per_block) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus = v;
+  }
+  per_block = cdiv(n_chunks, cus);
+  return cdiv(n_chunks, per_block);
+}
+
+static int agg_win_in(const AggDst& D) {  // in-conv to serve from the LDS ring, -1: none
+  if (D.F != 256 || D.n_rows < AGG_WIN_MIN_ROWS || D.ce_labels || (D.ldo & 3) || !D.zroot) return -1;
+  for (int ii = 0; ii < D.n_in; ++ii)  // every source matrix addressable by a 32-bit buffer offset below WIN_SKIP_OFF
+    if ((uint64_t)D.in[ii].n_src * (uint64_t)D.in[ii].ldz * 2 > (uint64_t)WIN_SKIP_OFF) return -1;
+  for (int ii = 0; ii < D.n_in; ++ii) {
+    const AggIn& I = D.in[ii];
+    if (I.same_type && !(I.coff & 7) && !(I.ldz & 7) && !(reinterpret_cast<uintptr_t>(I.z) & 15)) return ii;
+  }
+  return -1;
+}
+static int agg_win_out(const TAggSrc& S) {
+  if (S.n_rows < AGG_WIN_MIN_ROWS) return -1;
+  for (int oi = 0; oi < S.n_out; ++oi)
+    if ((uint64_t)S.out[oi].n_dst * (uint64_t)S.out[oi].ldg * 2 > (uint64_t)WIN_SKIP_OFF) return -1;
+  for (int oi = 0; oi < S.n_out; ++oi) {
+    const TAggOut& O = S.out[oi];
+    if (O.same_type && O.F == 256 && !(O.ldg & 7) && !(reinterpret_cast<uintptr_t>(O.g) & 15)) return oi;
+  }
+  return -1;
+}
+
 int agg_fwd_launch(AggArgs& a, hipStream_t st) {
   int Fmax = 0, blocks = 0;
   const int vec = 4;
@@ -948,6 +1497,45 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
   if (blocks == 0) return HMP_OK;
   if (a.zb16) {  // bf16 projected rows: only the one-wavefront-per-row shape reads them
     HMP_CHECK_ARG(gs == 64 && nv == 1, "agg_fwd: bf16 projected rows need row widths in (128, 256], got %d", Fmax);
+    if (agg_win_enabled()) {
+      // entries with a same-type edge type over >= 16384 rows go to the sliding-window kernel (one launch each, persistent
+      // grid of one workgroup per CU); the others stay in the plain launch below
+      AggArgs rest = a;
+      rest.n = 0;
+      bool any = false;
+      for (int i = 0; i < a.n; ++i) {
+        const int wi = agg_win_in(a.d[i]);
+        if (wi < 0) { rest.d[rest.n++] = a.d[i]; continue; }
+        static bool attr_done = false;
+        if (!attr_done) {
+          HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_fwd_win_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS_FWD));
+          HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_fwd_win_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS_FWD));
+          attr_done = true;
+        }
+        WinFwd w;
+        memset(&w, 0, sizeof(w));
+        w.d = a.d[i];
+        w.d.win_in = wi;
+        w.mean = a.mean;
+        w.n_chunks = cdiv(w.d.n_rows, WR);
+        const int grid = agg_win_grid(w.n_chunks, w.chunks_per_block);
+        if (a.hb16) hipLaunchKernelGGL((agg_fwd_win_kernel<true>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);
+        else hipLaunchKernelGGL((agg_fwd_win_kernel<false>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);
+        HMP_LAUNCH_CHECK();
+        any = true;
+      }
+      if (any) {
+        if (rest.n == 0) return HMP_OK;
+        a = rest;
+        blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+          a.d[i].block_start = blocks;
+          const int nb = cdiv(a.d[i].n_rows, 256 / gs);
+          blocks += a.xcd ? ((nb + 7) & ~7) : nb;
+        }
+        a.total_blocks = blocks;
+      }
+    }
     if (a.hb16) hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true, true>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true>), dim3(blocks), dim3(256), 0, st, a);
     HMP_LAUNCH_CHECK();
@@ -1011,9 +1599,47 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
   }
   a.total_blocks = blocks;
   if (blocks == 0 && !a.fin_row_lv) return HMP_OK;
-  const int grid = blocks + (a.fin_row_lv ? 1 : 0);
+  int grid = blocks + (a.fin_row_lv ? 1 : 0);
   if (a.gb16) {  // bf16 gradient rows: only the one-wavefront-per-row shape reads them
     HMP_CHECK_ARG(gs == 64 && nv == 1, "agg_bwd: bf16 gradient rows need row widths in (128, 256], got %d", Fmax);
+    if (agg_win_enabled()) {
+      TAggArgs rest = a;
+      rest.n = 0;
+      bool any = false;
+      for (int i = 0; i < a.n; ++i) {
+        const int wo = agg_win_out(a.s[i]);
+        if (wo < 0) { rest.s[rest.n++] = a.s[i]; continue; }
+        static bool attr_done = false;
+        if (!attr_done) {
+          HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_bwd_win_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS_BWD));
+          HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_bwd_win_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS_BWD));
+          attr_done = true;
+        }
+        WinBwd w;
+        memset(&w, 0, sizeof(w));
+        w.s = a.s[i];
+        w.s.win_out = wo;
+        w.mean = a.mean;
+        w.n_chunks = cdiv(w.s.n_rows, WR);
+        const int wgrid = agg_win_grid(w.n_chunks, w.chunks_per_block);
+        if (a.dzb16) hipLaunchKernelGGL((agg_bwd_win_kernel<true>), dim3(wgrid), dim3(WIN_THREADS), WIN_LDS_BWD, st, w);
+        else hipLaunchKernelGGL((agg_bwd_win_kernel<false>), dim3(wgrid), dim3(WIN_THREADS), WIN_LDS_BWD, st, w);
+        HMP_LAUNCH_CHECK();
+        any = true;
+      }
+      if (any) {
+        a = rest;
+        blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+          a.s[i].block_start = blocks;
+          const int nb = cdiv(a.s[i].n_rows, 256 / gs);
+          blocks += a.xcd ? ((nb + 7) & ~7) : nb;
+        }
+        a.total_blocks = blocks;
+        if (blocks == 0 && !a.fin_row_lv) return HMP_OK;
+        grid = blocks + (a.fin_row_lv ? 1 : 0);
+      }
+    }
     if (a.dzb16) hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true, true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true, false>), dim3(grid), dim3(256), 0, st, a);
     HMP_LAUNCH_CHECK();

@@ -60,35 +60,42 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
   do {                                                                             \
     if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = wall_clock64();           \
   } while (0)
+// accumulating form: kt_buf[i] += now - t0 (t0 from KT_NOW()); thread 0 of block 0 only
+#define KT_NOW() wall_clock64()
+#define KT_ADD(i, t0)                                                               \
+  do {                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] += wall_clock64() - (t0);    \
+  } while (0)
+#define KT_ZERO(i)                                                 \
+  do {                                                             \
+    if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = 0;        \
+  } while (0)
 #else
 #define KT_DEFINE(tag)
 #define KT(i) \
   do {        \
   } while (0)
+#define KT_NOW() 0ull
+#define KT_ADD(i, t0) \
+  do {                \
+    (void)(t0);       \
+  } while (0)
+#define KT_ZERO(i) \
+  do {             \
+  } while (0)
 #endif
 
-// ---- Philox4x32-10 (counter based; the same element always draws the same number, so the
-//      backward pass regenerates the forward's keep-mask instead of storing it) ------------------
-struct Philox4 {
-  uint32_t v[4];
-};
-
-__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                 uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += W0; k1 += W1;
-  }
-  Philox4 o;
-  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
-  return o;
+// ---- dropout RNG: counter based (the same element of the same tensor at the same step always draws the same number, so a
+//      mask can be regenerated instead of stored, and tests replay it through hmp_dropout_mask).  Round 1 used Philox4x32-10:
+//      40 32x32 -> 64-bit multiplies (quarter rate on the vector ALU) per 4 decisions made the RNG the largest single cost of
+//      the 256-wide aggregation epilogue (rocprofv3, config 5).  A dropout mask needs decorrelated bits, not a crypto-grade
+//      stream: two rounds of a 32-bit avalanche hash (xorshift-multiply, "lowbias32" constants) give one word = two 16-bit
+//      draws; 4 multiplies per 4 decisions.  p is resolved to 2^-16.
+__host__ __device__ inline uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
 
 // RNG coordinates of one dropout site: (seed, step) make the key, `stream` numbers the tensor
@@ -116,10 +123,16 @@ __host__ __device__ inline uint32_t drop_thresh(float p) {
 }
 
 // keep flags for the 4 consecutive elements 4*q .. 4*q+3 of the tensor numbered cfg.stream
-__device__ inline void drop_keep4(const DropCfg& cfg, uint32_t q, bool keep[4]) {
-  Philox4 r = philox4x32_10(q, cfg.stream, cfg.step, 0x48594452u, cfg.k0, cfg.k1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) keep[i] = r.v[i] >= cfg.thresh;
+__host__ __device__ inline void drop_keep4(const DropCfg& cfg, uint32_t q, bool keep[4]) {
+  // (stream, step, seed) fold into a wave-uniform key; the quad index is the counter
+  const uint32_t key = cfg.k0 ^ (cfg.stream * 0x9E3779B1u) ^ (cfg.step * 0x85EBCA77u);
+  const uint32_t a = hash32(q ^ key);
+  const uint32_t b = hash32((a + 0x9E3779B9u) ^ cfg.k1 ^ (q * 0xC2B2AE3Du));
+  const uint32_t t16 = cfg.thresh >> 16;
+  keep[0] = (a & 0xffffu) >= t16;
+  keep[1] = (a >> 16) >= t16;
+  keep[2] = (b & 0xffffu) >= t16;
+  keep[3] = (b >> 16) >= t16;
 }
 
 }  // namespace hmp

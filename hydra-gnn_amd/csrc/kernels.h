@@ -146,6 +146,8 @@ struct AggIn {
   const int* col;
   const float* z;  // projected source rows
   int ldz, coff;
+  int same_type;   // source node type == destination node type (one index space): candidate for the LDS-windowed gather
+  int n_src;       // rows of z
 };
 struct AggDst {
   int n_rows, F;
@@ -170,6 +172,7 @@ struct AggDst {
   int ce_classes, ce_ldg;
   float* ce_grad;
   float* ce_row_lv;
+  int win_in, win_src_rows;  // filled by agg_fwd_launch: in-conv served from the LDS window (-1: none), rows of its source
   AggIn in[AGG_MAX_IN];
 };
 struct AggArgs {
@@ -179,6 +182,7 @@ struct AggArgs {
   int xcd;   // large launches: consecutive row ranges stay on one XCD (block counts padded to 8 per entry), see agg_fwd_launch
   int zb16;  // the projected rows (AggIn::z, AggDst::zroot) hold bf16 elements (bf16 compute mode, 256-wide rows)
   int hb16;  // with zb16: the outputs (AggDst::out) are WRITTEN as bf16 elements too (activations of a hidden layer, read only by GEMMs)
+  int win_R, win_W;  // LDS-windowed launch (agg_fwd_win_kernel): destination rows per workgroup / source rows staged
   NetState* state;  // status bits (fused cross entropy: label out of range)
   AggDst d[HMP_MAX_NODE_TYPES];
 };
@@ -193,6 +197,8 @@ struct TAggOut {
   const float* degf;  // 1 / max(deg,1) per destination (plan by-product), null: derive from rowptr
   const float* g;     // gradient rows of the destination type
   int ldg, coff, F;
+  int same_type;      // destination node type == source node type: candidate for the LDS-windowed gather
+  int n_dst;          // rows of g
 };
 struct TAggSrc {
   int n_rows;
@@ -208,6 +214,7 @@ struct TAggSrc {
   const float* xh;  // activations whose derivative masks xg (null: none)
   int xldw, xN, xldg, xldh, xact, xdrop_on;
   float xscale;
+  int win_out, win_dst_rows;  // filled by agg_bwd_launch (see AggDst::win_in)
   TAggOut out[AGG_MAX_IN];
 };
 struct TAggArgs {
@@ -217,6 +224,7 @@ struct TAggArgs {
   int xcd;  // as AggArgs::xcd
   int gb16; // the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements
   int dzb16; // dz is written as bf16 (requires gb16)
+  int win_R, win_W;  // LDS-windowed launch (agg_bwd_win_kernel)
   // one extra block sums the per-row {loss, valid} pairs of the loss in fixed order -> fin_out2 / fin_state (null: off)
   const float* fin_row_lv;
   int fin_rows;

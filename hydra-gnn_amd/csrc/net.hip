@@ -965,6 +965,8 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           I.rowptr = n->plan[C.edge_type].d_rowptr;
           I.col = n->plan[C.edge_type].d_col;
           I.z = n->Z[l][C.src]; I.ldz = Y.ncols[C.src]; I.coff = Y.conv[c].coff;
+          I.same_type = C.src == C.dst ? 1 : 0;
+          I.n_src = b->n_nodes[C.src];
         }
       }
       // fuse the projection of layer l+1 when every node type it reads is produced right here
@@ -1121,6 +1123,8 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           int ldg;
           O.g = g_of(C.dst, ldg);
           O.ldg = ldg; O.coff = Y.conv[c].coff; O.F = fpad(C.f_out);
+          O.same_type = C.src == C.dst ? 1 : 0;
+          O.n_dst = b->n_nodes[C.dst];
         }
       }
       // input gradient of layer l inside the same kernel (row-local GEMM on 16-row tiles) for small batches

@@ -115,7 +115,7 @@ typedef struct hmp_gat_args {
   int32_t self_loops;
   int32_t edge_dim;          /* 0..4 */
   float dropout_p;           /* attention dropout; 0 = off */
-  uint64_t seed;             /* dropout RNG (Philox4x32-10): element (pos, h) of an [E + n_loop, 8] tensor, */
+  uint64_t seed;             /* dropout RNG (counter hash, csrc/common.h): element (pos, h) of an [E + n_loop, 8] tensor, */
   uint32_t rng_stream, rng_step; /* pos = CSR position of the edge, loops at E + i (see hmp_dropout_mask) */
 } hmp_gat_args;
 

@@ -135,10 +135,11 @@ def test_config5_fp32_mode_matches_the_float64_oracle(graph):
             assert grads[name] is None, name
             continue
         assert grads[name] is not None, name
-        # a weight-gradient element is a sum over up to 40 000 nodes x 16 edges of fp32 products of either sign: compared at
-        # 1e-5 of the tensor's scale plus 1e-5 relative per element
+        # a weight / bias gradient element is a sum over up to 40 000 nodes x 16 edges of fp32 products of either sign: fp32
+        # accumulation alone leaves ~sqrt(40 000) x 2^-24 = 1.2e-5 of the tensor's scale (measured worst 1.1e-5 .. 1.7e-5 over
+        # dropout masks): compared at 3e-5 of the scale plus 1e-5 relative per element
         scale = float(q.grad.abs().max())
-        torch.testing.assert_close(grads[name].double(), q.grad, atol=1e-5 * scale, rtol=1e-5, msg=lambda m: f"{name}: {m}")
+        torch.testing.assert_close(grads[name].double(), q.grad, atol=3e-5 * scale, rtol=1e-5, msg=lambda m: f"{name}: {m}")
         worst = max(worst, nerr(grads[name], q.grad))
     print(f"config-5 shape, fp32 mode vs float64 oracle: logits {nerr(pred, pred_ref.detach()):.2e}, worst gradient {worst:.2e} of "
           f"its scale; ReLU units within 1e-5 of zero: {stats['ambiguous']}, of which the two sides disagreed on {stats['flipped']}")

@@ -321,6 +321,53 @@ def test_bf16_mode_activation_storage_is_bit_identical(n_obj, n_rooms):
     assert not torch.equal(net(g), out)
 
 
+@pytest.mark.parametrize("n_obj,n_rooms,shuffle", [(40000, 400, False), (140000, 1400, False), (40000, 400, True)])
+def test_lds_windowed_aggregation_is_bit_identical(n_obj, n_rooms, shuffle, monkeypatch):
+    """bf16 mode, 256-wide layers, >= 16384 rows: persistent workgroups keep a sliding ring of source rows in LDS and serve
+    in-window neighbours from there (agg_fwd_win_kernel / agg_bwd_win_kernel).  Same sums in the same edge order: logits and
+    every gradient are BIT-identical to the plain one-wave-per-row kernels (HMP_AGG_WIN=0), also when the numbering has no
+    locality at all (object ids shuffled: nearly every neighbour takes the prefetch-slot / direct global path, many more
+    than the slots hold) and in training mode with dropout."""
+    monkeypatch.setenv("HMP_BF16_ALL", "1")
+    kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, dropout=0.25)
+    g = workloads.big_hetero_graph(n_obj=n_obj, n_rooms=n_rooms, seed=13)
+    if shuffle:  # relabel the objects at random: destroys the locality the window relies on, not the graph
+        perm = torch.randperm(n_obj, generator=torch.Generator().manual_seed(5))
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n_obj)
+        g["objects"].x = g["objects"].x[perm]
+        oo = ("objects", "objects_to_objects", "objects")
+        g[oo].edge_index = inv[g[oo].edge_index]
+        o2r = ("objects", "objects_to_rooms", "rooms")
+        ei = g[o2r].edge_index.clone(); ei[0] = inv[ei[0]]; g[o2r].edge_index = ei
+        r2o = ("rooms", "rooms_to_objects", "objects")
+        ei = g[r2o].edge_index.clone(); ei[1] = inv[ei[1]]; g[r2o].edge_index = ei
+    g = g.to(DEV)
+    _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+    net.train()
+    net.native().set_compute("bf16")
+    y = g["rooms"].y
+
+    def fwd_bwd():
+        net._rng_step = 0
+        for p in net.parameters():
+            p.grad = None
+        pred = net(g)
+        net.loss(pred, y, y != 25).backward()
+        return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv("HMP_AGG_WIN", "0")
+    ref, gref = fwd_bwd()
+    assert net.native().read_state()[1] == 0
+    monkeypatch.delenv("HMP_AGG_WIN")
+    out, grads = fwd_bwd()
+    assert torch.equal(out, ref)
+    assert set(grads) == set(gref)
+    for k in grads:
+        assert torch.equal(grads[k], gref[k]), k
+    assert net.native().read_state()[1] == 0
+
+
 @pytest.mark.parametrize("hidden", [64, 256])
 def test_large_launch_xcd_row_mapping_is_bit_identical(hidden, monkeypatch):
     """>= 65536 rows: the aggregation kernels hand every XCD one contiguous eighth of the rows (L2 locality).  Which block

@@ -170,6 +170,96 @@ def test_hetero_gat_edge_parity(hidden, heads, concats):
     check_model(ora, net, workloads.mp3d_like_batch(5, seed=22, relative_pos=True))
 
 
+def make_gat_replay(net, batch):
+    """dropout_fn for the oracle that replays the keep-masks the ENGINE drew in its last training forward: feature dropout per
+    (layer, node type) and attention dropout per (layer, conv).  The engine numbers an attention element (pos, h) in an
+    [E + n_loop, 8] tensor, pos = position of the edge in the destination-sorted (stable) list, self loops at E + node
+    (include/hydra_mp.h, hmp_gat_args); the oracle's list is [original edges without self loops..., loop 0, loop 1, ...]."""
+    lib = _lib.require_device()
+    nt = {"objects": 0, "rooms": 1}
+    ets = list(omodels.EDGE_TYPES)
+
+    def mask(stream, pp, n, F):
+        m = torch.zeros(n * F, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.hmp_dropout_mask(net._seed, net._rng_step, stream, pp, n, F, m.data_ptr(), _lib.stream_ptr()))
+        return m.view(n, F).cpu()
+
+    def replay(x, pp, training, tag):
+        if not training or pp == 0:
+            return x
+        if not tag.endswith(".alpha"):
+            layer, t = tag[1:].split(".", 1)
+            keep = mask(int(layer) * 8 + nt[t], pp, x.size(0), x.size(1))
+            return x * keep.to(x.dtype) / (1.0 - pp)
+        layer, name = tag[1:-len(".alpha")].split(".", 1)
+        et = tuple(name.split("__"))
+        ei = batch[et].edge_index
+        E = ei.size(1)
+        loops = et[0] == et[2]
+        n_loop = min(batch[et[0]].x.size(0), batch[et[2]].x.size(0)) if loops else 0
+        m = mask(1000 + int(layer) * 16 + ets.index(et), pp, E + n_loop, 8)
+        order = torch.sort(ei[1], stable=True).indices
+        pos_of = torch.empty(E, dtype=torch.int64)
+        pos_of[order] = torch.arange(E)
+        rows = torch.cat([pos_of[ei[0] != ei[1]], E + torch.arange(n_loop)]) if loops else pos_of
+        assert rows.numel() == x.size(0)
+        keep = m[rows][:, : x.size(1)]
+        return x * keep.to(x.dtype) / (1.0 - pp)
+
+    return replay
+
+
+@pytest.mark.parametrize("block,hidden,heads,concats", [
+    ("GAT", [128, 128], [4, 4, 4], [True, True, False]),        # BASELINE config 3: the timed path
+    ("GAT_edge", [128, 128], [4, 4, 4], [True, True, False]),
+    ("GAT_edge", [64, 64], [3, 3, 3], [False, False, False]),   # the shipped MP3D shape (config/mp3d/baseline_gt60.yaml)
+])
+def test_gat_training_mode_parity_with_replayed_masks(block, hidden, heads, concats):
+    """Training mode as train_mp3d.py runs it (dropout 0.25 on the attention coefficients AND on the ELU outputs): the oracle
+    replays the engine's Philox keep-masks; logits, loss and every gradient at 1e-5.  (models/utils.py:31-87)"""
+    p = 0.25
+    ora, net = gat_pair(block, hidden, heads, concats, dropout=p)
+    batch = workloads.mp3d_like_batch(6, seed=29, relative_pos=(block == "GAT_edge"))
+    net.train()
+    pred = net(batch.to(DEV))
+    replay = make_gat_replay(net, batch)
+    ora.dropout_fn = replay
+    for m in ora.modules():
+        if isinstance(m, pyg_ref.GATConv):
+            m.dropout_fn = replay
+    o64 = copy.deepcopy(ora).double()
+    o64.train()
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    for et in b64.edge_types:
+        if "edge_attr" in b64[et]:
+            b64[et].edge_attr = b64[et].edge_attr.double()
+    y = batch["rooms"].y
+    pred_ref = o64(b64)
+    loss_ref = o64.loss(pred_ref, y, y != 25)
+    loss_ref.backward()
+    torch.testing.assert_close(pred.cpu().double(), pred_ref.detach(), atol=ATOL, rtol=RTOL)
+    yg = y.to(DEV)
+    loss = net.loss(pred, yg, yg != 25)
+    torch.testing.assert_close(loss.detach().cpu().double(), loss_ref.detach(), atol=ATOL, rtol=RTOL)
+    loss.backward()
+    og = dict(o64.named_parameters())
+    n = 0
+    for name, q in net.named_parameters():
+        ref = og[name].grad
+        if ref is None:
+            assert q.grad is None, f"{name}: unexpected gradient"
+            continue
+        assert q.grad is not None, f"{name}: missing gradient"
+        torch.testing.assert_close(q.grad.cpu().double(), ref, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
+        n += 1
+    assert n > 20
+    # the masks really acted: the eval-mode logits differ
+    net.eval()
+    assert not torch.allclose(net(batch.to(DEV)), pred, atol=1e-3)
+
+
 def test_gat_training_mode_runs_and_is_deterministic():
     _, net = gat_pair("GAT_edge", [32, 32], [2, 2, 2], [True, True, False], dropout=0.4)
     batch = workloads.mp3d_like_batch(4, seed=23, relative_pos=True).to(DEV)
