@@ -149,6 +149,10 @@ SIGNATURES = {
     "hmp_rowdot_sum": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP]),
     "hmp_batchnorm_fwd": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _F32, _F32, _I32, _VP, _I32, _VP, _VP]),
     "hmp_batchnorm_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP, _I32, _VP, _VP, _VP]),
+    "hmp_htree_build": (C.c_int, [_I32, _I32, _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
+    "hmp_htree_sizes": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)]),
+    "hmp_htree_fill": (C.c_int, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "hmp_htree_destroy": (None, [_VP]),
     "hmp_comm_unique_id": (C.c_int, [_VP]),
     "hmp_comm_create": (C.c_int, [_VP, _I32, _I32, C.POINTER(_VP)]),
     "hmp_comm_destroy": (None, [_VP]),

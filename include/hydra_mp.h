@@ -381,6 +381,25 @@ void hmp_comm_destroy(hmp_comm* comm);
 int hmp_comm_allreduce_sum_f32(hmp_comm* comm, float* d_buf, int64_t n, void* stream);
 int hmp_comm_broadcast_f32(hmp_comm* comm, float* d_buf, int64_t n, int32_t root, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 12. H-tree (Neural-Tree) construction on the host (csrc/htree.cpp).  Replaces generate_htree +
+ *     add_virtual_nodes_to_htree + the typed extraction of nx_htree_to_torch (src/hydra_gnn/neural_tree/construct.py:241-371,
+ *     450-468) and generate_jth / networkx.junction_tree underneath (generate_junction_tree_hierarchies.py:26-116).
+ *     Input: a room-object scene graph -- object-object, room-room and room->object edge lists [2][E] int64 (undirected: either
+ *     or both directions may be listed).  Output (hmp_htree_sizes, then hmp_htree_fill into caller arrays, all int32):
+ *       counts[4]       nodes per type: object, room, object-room, room-room (leaves are COPIES of scene-graph nodes)
+ *       object_orig / room_orig   original index (inside its type) of every object / room leaf  == the pool edges o_to_ov / r_to_rv
+ *       edges[10]       [2][n] local indices for HTREE_EDGE_TYPES in the reference's order (construct.py:15-26), both directions
+ *       init[3]         [2][n] ov_to_or, rv_to_or, rv_to_rr: (original index of the member, clique)
+ *     Ties that networkx leaves to Python set order go to the smallest index (see the file header).  Host memory only.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hmp_htree hmp_htree; /* opaque */
+int hmp_htree_build(int32_t n_objects, int32_t n_rooms, const int64_t* oo_edges, int64_t n_oo, const int64_t* rr_edges,
+                    int64_t n_rr, const int64_t* ro_edges, int64_t n_ro, hmp_htree** out);
+int hmp_htree_sizes(const hmp_htree* t, int32_t* counts4, int64_t* n_edges10, int64_t* n_init3);
+int hmp_htree_fill(const hmp_htree* t, int32_t* object_orig, int32_t* room_orig, int32_t* const* edges10, int32_t* const* init3);
+void hmp_htree_destroy(hmp_htree* t);
+
 #ifdef __cplusplus
 }
 #endif

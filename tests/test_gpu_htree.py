@@ -228,3 +228,29 @@ def test_htree_two_head_task_parity(block, init):
     net.load_state_dict(ora.state_dict(), strict=True)
     batch = workloads.htree_batch(4, seed=37)
     two_head_check(ora, net.to(DEV), batch, to64(batch))
+
+
+def test_natively_built_htrees_drive_the_model():
+    """scene graphs -> hmp_htree_* (csrc/htree.cpp) -> collate -> HeterogeneousNeuralTreeNetwork with pre_mp initialisation
+    (it reads the init edges and the virtual nodes the construction emits): engine == oracle on the same H-trees."""
+    import numpy as np
+
+    from hydra_gnn_amd import htree
+    from hydra_gnn_amd.data import collate
+
+    torch.manual_seed(2)
+    kw = dict(input_dim_dict=HT_DIMS, output_dim=26, conv_block="GraphSAGE", hidden_dim=32, num_layers=3, disable_initialization=False,
+              dropout=0.0)
+    ora = omodels.HeterogeneousNeuralTreeNetwork(**kw)
+    net = HeterogeneousNeuralTreeNetwork(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net = net.to(DEV).eval()
+    rng = np.random.default_rng(17)
+    trees = [htree.generate_htree(workloads.mp3d_like_graph(rng, mean_in_degree=2.0), clique_dim=6) for _ in range(5)]
+    batch = collate(trees)
+    assert batch["room_virtual"].x.size(0) == sum(t["room_virtual"].x.size(0) for t in trees)
+    o64 = copy.deepcopy(ora).double().eval()
+    pred_ref = o64(to64(batch))
+    pred = net(batch.to(DEV))
+    assert pred.shape == (batch["room_virtual"].x.size(0), 26)
+    compare(net, o64, pred, pred_ref, batch["room_virtual"].y)

@@ -1,0 +1,197 @@
+"""csrc/htree.cpp (hmp_htree_*) against H-trees built by the REFERENCE's own junction-tree-hierarchy generator
+(tests/golden/htree_reference_cases.npz, made by tests/golden/make_htree_native_fixture.py in the build container).
+
+networkx leaves ties to Python set iteration order, the native code to the smallest index (csrc/htree.cpp header), so:
+* scene graphs whose object / room graphs are trees, complete graphs, paths, stars or edgeless -- maximal cliques and
+  separator incidences do not depend on ties -- must give the SAME labelled H-tree (node multiset by (type, content), edge
+  multiset by endpoint contents);
+* loopy graphs (a chordal completion has to choose fill edges) must satisfy the structural rules of the construction
+  (construct.py:87-236): every clique holds exactly the right kinds of members, every scene-graph edge is covered by a clique,
+  leaves hang off cliques that contain them, both directions of every edge type are present -- and are compared with the
+  reference for information.
+Host code only: runs without a GPU."""
+import collections
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hydra_gnn_amd import htree
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "htree_reference_cases.npz")
+NT = ["object", "room", "object-room", "room-room"]
+ET = [(0, 2), (2, 0), (1, 2), (2, 1), (1, 3), (3, 1), (2, 3), (3, 2), (2, 2), (3, 3)]  # HTREE_EDGE_TYPES as (src type, dst type)
+UNIQUE = ["paths", "stars", "cliques", "rtrees", "singletons", "one_room", "isolated_objects", "rtrees_big"]
+LOOPY = ["loopy_a", "loopy_b", "loopy_c"]
+
+
+def load(name):
+    z = np.load(GOLDEN)
+    n_obj, n_rooms = [int(v) for v in z[f"{name}_n"]]
+    scene = (n_obj, n_rooms, torch.from_numpy(z[f"{name}_oo"]), torch.from_numpy(z[f"{name}_rr"]), torch.from_numpy(z[f"{name}_ro"]))
+    ref = {"counts": z[f"{name}_counts"].tolist(), "object_orig": z[f"{name}_object_orig"], "room_orig": z[f"{name}_room_orig"],
+           "edges": [z[f"{name}_e{k}"].reshape(2, -1) for k in range(10)], "init": [z[f"{name}_i{k}"].reshape(2, -1) for k in range(3)]}
+    return scene, ref
+
+
+def contents(t):
+    """label of every node: leaves ('o', id) / ('r', id); cliques (type, sorted object members, sorted room members)"""
+    lab = {0: [("o", int(i)) for i in t["object_orig"]], 1: [("r", int(i)) for i in t["room_orig"]]}
+    mem = {2: collections.defaultdict(lambda: ([], [])), 3: collections.defaultdict(lambda: ([], []))}
+    for s, d in t["init"][0].T:
+        mem[2][int(d)][0].append(int(s))
+    for s, d in t["init"][1].T:
+        mem[2][int(d)][1].append(int(s))
+    for s, d in t["init"][2].T:
+        mem[3][int(d)][1].append(int(s))
+    for ty in (2, 3):
+        lab[ty] = [(NT[ty], tuple(sorted(mem[ty][i][0])), tuple(sorted(mem[ty][i][1]))) for i in range(t["counts"][ty])]
+    return lab
+
+
+def signature(t):
+    lab = contents(t)
+    nodes = collections.Counter(l for ty in range(4) for l in lab[ty])
+    edges = collections.Counter()
+    for k, (ts, td) in enumerate(ET):
+        for s, d in t["edges"][k].T:
+            edges[(lab[ts][int(s)], lab[td][int(d)])] += 1
+    return nodes, edges
+
+
+def check_rules(scene, t):
+    n_obj, n_rooms, oo, rr, ro = scene
+    lab = contents(t)
+    room_of = {int(o): int(r) for r, o in ro.T.tolist()}
+    assert len(t["object_orig"]) == t["counts"][0] and len(t["room_orig"]) == t["counts"][1]
+    # both directions of every edge type
+    for a, b in ((0, 1), (2, 3), (4, 5), (6, 7)):
+        fw = collections.Counter(map(tuple, t["edges"][a].T.tolist()))
+        bw = collections.Counter((d, s) for s, d in t["edges"][b].T.tolist())
+        assert fw == bw
+    for k in (8, 9):
+        e = collections.Counter(map(tuple, t["edges"][k].T.tolist()))
+        assert e == collections.Counter((d, s) for (s, d) in e.elements())
+    # object-room cliques: exactly one room, objects of that room only; room-room cliques: rooms only, at least one
+    for _, objs, rooms in lab[2]:
+        assert len(rooms) == 1 and len(objs) >= 1 and all(room_of[o] == rooms[0] for o in objs)
+    for _, objs, rooms in lab[3]:
+        assert not objs and len(rooms) >= 1
+    # every scene-graph edge is covered by a clique; every object in a room sits in a clique and is a leaf
+    cov_o = collections.defaultdict(set)
+    for i, (_, objs, _) in enumerate(lab[2]):
+        for o in objs:
+            cov_o[o].add(i)
+    for a, b in oo.T.tolist():
+        if a in room_of and b in room_of and room_of[a] == room_of[b]:
+            assert cov_o[a] & cov_o[b], (a, b)
+    leaf_objs = set(int(i) for i in t["object_orig"])
+    for o in room_of:
+        assert cov_o[o] and o in leaf_objs
+    if n_rooms > 1:
+        cov_r = collections.defaultdict(set)
+        for i, (_, _, rooms) in enumerate(lab[3]):
+            for r in rooms:
+                cov_r[r].add(i)
+        for a, b in rr.T.tolist():
+            assert cov_r[a] & cov_r[b]
+    assert set(int(i) for i in t["room_orig"]) == set(range(n_rooms))
+    # a leaf hangs off cliques that contain it (object leaf -> object-room cliques; room leaf -> object-room / room-room)
+    for s, d in t["edges"][0].T:
+        assert int(t["object_orig"][s]) in lab[2][int(d)][1]
+    for s, d in t["edges"][2].T:
+        assert int(t["room_orig"][s]) in lab[2][int(d)][2]
+    for s, d in t["edges"][4].T:
+        assert int(t["room_orig"][s]) in lab[3][int(d)][2]
+    # clique - clique edges across levels: the child's members are a subset of the parent's or the two share members
+    for k, ty in ((8, 2), (9, 3)):
+        for s, d in t["edges"][k].T:
+            a, b = lab[ty][int(s)], lab[ty][int(d)]
+            assert (set(a[1]) | set(a[2])) & (set(b[1]) | set(b[2]))
+
+
+@pytest.mark.parametrize("name", UNIQUE)
+def test_tie_free_inputs_give_the_reference_htree(name):
+    scene, ref = load(name)
+    t = htree.htree_topology(*scene)
+    check_rules(scene, t)
+    assert t["counts"] == ref["counts"]
+    assert signature(t) == signature(ref)
+
+
+@pytest.mark.parametrize("name", LOOPY)
+def test_loopy_inputs_satisfy_the_construction_rules(name):
+    scene, ref = load(name)
+    t = htree.htree_topology(*scene)
+    check_rules(scene, t)
+    check_rules(scene, ref)  # the rules are the reference's own: its output satisfies them too
+    same = signature(t) == signature(ref)
+    print(f"{name}: native {t['counts']} reference {ref['counts']} identical labelled tree: {same}")
+    # the leaf SET is tie-independent (every object of a room, every room)
+    assert set(t["object_orig"].tolist()) == set(ref["object_orig"].tolist())
+    assert set(t["room_orig"].tolist()) == set(ref["room_orig"].tolist())
+
+
+def test_bad_inputs_are_refused():
+    from hydra_gnn_amd import _lib
+
+    e = torch.zeros(2, 0, dtype=torch.int64)
+    with pytest.raises(_lib.HydraMPError, match="out of range"):
+        htree.htree_topology(2, 1, torch.tensor([[0], [5]]), e, torch.tensor([[0, 0], [0, 1]]))
+    with pytest.raises(_lib.HydraMPError, match="without a room"):
+        htree.htree_topology(2, 1, e, e, torch.tensor([[0], [0]]))  # object 1 belongs to no room and has no neighbour
+
+
+def test_generate_htree_builds_the_model_input():
+    """scene-graph HeteroData -> H-tree HeteroData with the layout HeterogeneousNeuralTreeNetwork reads."""
+    from hydra_gnn_amd import workloads
+    from hydra_gnn_amd.data import HTREE_EDGE_TYPES, HTREE_INIT_EDGE_TYPES
+
+    g = workloads.mp3d_like_graph(np.random.default_rng(3), mean_in_degree=2.0)
+    ht = htree.generate_htree(g)
+    n_o, n_r = g["objects"].x.size(0), g["rooms"].x.size(0)
+    assert ht["object_virtual"].x.shape == g["objects"].x.shape and ht["room_virtual"].x.shape == g["rooms"].x.shape
+    assert ht["object"].x.size(1) == g["objects"].x.size(1) and ht["object-room"].x.size(1) == g["objects"].x.size(1)
+    assert ht["room-room"].x.size(1) == g["rooms"].x.size(1)
+    pool = ht["room", "r_to_rv", "room_virtual"].edge_index
+    assert torch.equal(ht["room"].x, g["rooms"].x[pool[1]]) and int(pool[1].max()) == n_r - 1
+    assert torch.equal(ht["room_virtual"].y, g["rooms"].y)
+    for et in list(HTREE_EDGE_TYPES) + list(HTREE_INIT_EDGE_TYPES):
+        ei = ht[et].edge_index
+        assert ei.dtype == torch.int64 and ei.size(0) == 2
+        if ei.numel():
+            assert int(ei[0].max()) < ht[et[0]].x.size(0) and int(ei[1].max()) < ht[et[2]].x.size(0)
+    # clique position = mean position of its rooms: an object-room clique has ONE room
+    rv = ht["room_virtual", "rv_to_or", "object-room"].edge_index
+    torch.testing.assert_close(ht["object-room"].x[rv[1], :3], g["rooms"].x[rv[0], :3])
+    assert float(ht["object-room"].x[:, 3:].abs().max()) == 0.0
+
+
+def test_config4_fixture_scene_graphs():
+    """The six MP3D-like scene graphs behind tests/golden/htree_topologies.npz (config-4 inputs, loopy object graphs, node ids
+    up to ~150): networkx walks Python SETS of those ids when it breaks ties, so its triangulations differ from the
+    smallest-index ones here -- the native H-trees must satisfy the construction rules, hold the same leaf sets, and stay
+    within the size range of a minimal triangulation of the same graphs (how many coincide is printed)."""
+    from hydra_gnn_amd import workloads
+
+    z = np.load(workloads.HTREE_FIXTURE)
+    rng = np.random.Generator(np.random.PCG64(workloads.BASE_SEED + 4))
+    same = 0
+    for gi in range(int(z["n_graphs"])):
+        g = workloads.mp3d_like_graph(rng, sem_dim=0, mean_in_degree=2.0)
+        assert g["objects"].x.size(0) == int(z[f"g{gi}_n_objects"]) and g["rooms"].x.size(0) == int(z[f"g{gi}_n_rooms"])
+        ei = g.edge_index_dict
+        scene = (g["objects"].x.size(0), g["rooms"].x.size(0), ei[htree.OO], ei[htree.RR], ei[htree.RO])
+        t = htree.htree_topology(*scene)
+        ref = {"counts": z[f"g{gi}_counts"].tolist(), "object_orig": z[f"g{gi}_object_orig"], "room_orig": z[f"g{gi}_room_orig"],
+               "edges": [z[f"g{gi}_e{k}"].reshape(2, -1) for k in range(10)], "init": [z[f"g{gi}_i{k}"].reshape(2, -1) for k in range(3)]}
+        check_rules(scene, t)
+        check_rules(scene, ref)
+        assert set(t["object_orig"].tolist()) == set(ref["object_orig"].tolist())
+        assert set(t["room_orig"].tolist()) == set(ref["room_orig"].tolist())
+        assert t["counts"][3] == ref["counts"][3]  # room graphs here are trees + few extra edges on <= 12 ids: tie-free
+        assert 0.6 * sum(ref["counts"]) <= sum(t["counts"]) <= 1.6 * sum(ref["counts"]), (t["counts"], ref["counts"])
+        same += int(t["counts"] == ref["counts"] and signature(t) == signature(ref))
+        print(f"fixture graph {gi}: native {t['counts']} reference {ref['counts']}")
+    print(f"{same} of {int(z['n_graphs'])} fixture H-trees coincide with the reference's")
