@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--min-timed-s", type=float, default=0.2,
                     help="the K-step timed region is repeated (each repeat bracketed by barrier + synchronize) until this much "
                          "time has been timed; `steps` stays K, `timed_regions` says how many")
+    ap.add_argument("--fresh-batches", action="store_true",
+                    help="extra leg (config 2 / 3): every step takes a DIFFERENT batch, collated on the device from a resident "
+                         "dataset of 64 x batch graphs (store.BatchStream: one host call + one kernel) and described afresh -- "
+                         "the loop a trainer actually runs; reported as `fresh_batches` beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -452,6 +456,47 @@ def main():
             "host_enqueue_us_per_step": round(host_us, 1),
         },
     }
+
+    # ---- fresh-batch leg: the loop a trainer runs -- a new batch every step (base_training_job.py:202-216) --------------------
+    if args.fresh_batches and args.config in (2, 3) and world == 1:
+        from hydra_gnn_amd import workloads
+        from hydra_gnn_amd.store import GraphStore
+
+        n_pool = 64 * n_graphs
+        rng_p = np.random.Generator(np.random.PCG64(workloads.BASE_SEED + 77))
+        pool = [workloads.mp3d_like_graph(rng_p) for _ in range(n_pool)]
+        store = GraphStore(pool, dev)
+        fstep = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=20250225, use_graph=False)
+        stream = store.stream(net, n_graphs, label_type)
+        perm = np.random.Generator(np.random.PCG64(5)).permutation(n_pool).astype(np.int32)
+        batches = [perm[i * n_graphs:(i + 1) * n_graphs] for i in range(n_pool // n_graphs)]
+        nb = len(batches)
+        for i in range(args.warmup):
+            fstep.run(stream.next(batches[i % nb]))
+        f_steps = max(args.steps, 200)
+        f_regions = []
+        for _ in range(5):
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(f_steps):
+                fstep.run(stream.next(batches[i % nb]))
+            sync_all()
+            f_regions.append(time.perf_counter() - t0)
+        sync_all()
+        th = time.perf_counter()
+        for i in range(50):
+            fstep.run(stream.next(batches[i % nb]))
+        f_host_us = 1e6 * (time.perf_counter() - th) / 50
+        sync_all()
+        f_ms = 1e3 * min(f_regions) / f_steps
+        out["fresh_batches"] = {
+            "ms_per_step": round(f_ms, 5), "graphs_per_s": round(n_graphs / (f_ms * 1e-3), 1),
+            "vs_resident_batch": round(f_ms / ms_per_step, 3), "host_enqueue_us_per_step": round(f_host_us, 1),
+            "steps": f_steps, "regions": 5, "pool_graphs": n_pool,
+            "what": "every step: device collation of a new batch of the resident dataset (1 kernel) + descriptor + the training step",
+        }
+        assert net.native().read_state()[1] == 0
+        stream.close()
 
     # ---- roofline leg: HIP events around every launch of each kernel family, eager launches, executor streams ----------
     if rank == 0 and not args.no_roofline:

@@ -88,6 +88,11 @@ class TrainArgs(C.Structure):
     ]
 
 
+class CollateItem(C.Structure):
+    _fields_ = [("d_src", C.c_void_p), ("d_ptr", C.c_void_p), ("src_total", C.c_int64), ("row_bytes", C.c_int64),
+                ("slot", C.c_int32), ("slot_src", C.c_int32), ("slot_dst", C.c_int32)]
+
+
 _STRUCTS = [Plan, GatArgs, ConvSpec, LayerSpec, NetSpec, Batch, TrainArgs]
 
 _VP, _I32, _I64, _F32, _U64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32
@@ -149,6 +154,9 @@ SIGNATURES = {
     "hmp_rowdot_sum": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP]),
     "hmp_batchnorm_fwd": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _F32, _F32, _I32, _VP, _I32, _VP, _VP]),
     "hmp_batchnorm_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP, _I32, _VP, _VP, _VP]),
+    "hmp_collator_create": (C.c_int, [_I32, C.POINTER(_VP), _I64, _I32, C.POINTER(CollateItem), C.POINTER(_VP)]),
+    "hmp_collator_run": (C.c_int, [_VP, _VP, _I32, C.POINTER(_VP), C.POINTER(_I64), C.POINTER(_I64), _VP]),
+    "hmp_collator_destroy": (None, [_VP]),
     "hmp_htree_build": (C.c_int, [_I32, _I32, _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
     "hmp_htree_sizes": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)]),
     "hmp_htree_fill": (C.c_int, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(_VP)]),

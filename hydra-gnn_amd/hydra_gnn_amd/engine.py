@@ -625,6 +625,23 @@ class TrainStep:
         except Exception:
             pass
 
+    def run(self, holder: _BatchHolder) -> None:
+        """One training step on a batch that is already described (``store.BatchStream.next``): no per-tensor Python, no
+        descriptor cache -- the path a data loader that lives on the device drives.  Eager launches."""
+        net = self.net
+        if self.use_graph:
+            raise _lib.HydraMPError("TrainStep.run steps a NEW batch every call: create the step with use_graph=False")
+        net._fwd_token += 1
+        self._batch_key = None
+        self._holder = holder
+        st = _lib.stream_ptr()
+        if self._world() == 1 and not self.force_collective:
+            self._phase_ab(holder, st)
+        else:
+            self._phase_a(holder, st)
+            self._all_reduce()
+            self._phase_b(st)
+
     def set_lr(self, lr: float) -> None:
         """Follow a learning-rate scheduler (``StepLR`` in ``base_training_job.py:186-188``): takes effect with the next
         step.  Captured graphs carry the rate as a kernel argument and are re-captured."""

@@ -145,3 +145,159 @@ class GraphStore:
                                                 ea.data_ptr(), st))
                 out[e].edge_attr = ea
         return out
+
+
+class BatchStream:
+    """A DataLoader's inner loop for ONE network, without the DataLoader: every :meth:`next` assembles a fresh batch of
+    ``batch_size`` graphs on the device (``hmp_collator_run``: one host call, one kernel, outputs in buffers allocated once) and
+    hands back the executor's batch descriptor ready made -- no per-tensor Python between two training steps
+    (``base_training_job.py:202-216`` spends it in ``DataLoader.__next__`` + ``batch.to(device)`` + ``make_batch``).
+
+        stream = store.stream(model, batch_size=32, label_type="rooms")
+        for ids in sampler:                  # e.g. a shuffled permutation cut into batches
+            step.run(stream.next(ids))       # TrainStep.run: fwd + loss + bwd + Adam on that batch
+
+    The buffers are reused by the next call: a batch is valid until then (same-stream ordering makes that safe for everything
+    already enqueued).  ``stream.data()`` presents the current batch as a ``HeteroData`` of views for code that wants one."""
+
+    def __init__(self, store: "GraphStore", net, batch_size: int, label_type: str, label_key: str = "y"):
+        import ctypes as C
+
+        self.store, self.B = store, int(batch_size)
+        self.net = net
+        lib = store.lib
+        dev = store.device
+        slots: List[object] = list(store.node_types) + list(store.edge_types)
+        slot_of = {k: i for i, k in enumerate(slots)}
+        host_ptrs = []
+        for t in store.node_types:
+            host_ptrs.append(np.concatenate([[0], np.cumsum(store.node_counts[t])]).astype(np.int64))
+        for e in store.edge_types:
+            host_ptrs.append(np.ascontiguousarray(store.edge_ptr_host[e], dtype=np.int64))
+        self._host_ptrs = host_ptrs
+        self._node_ptr_dev = {t: torch.from_numpy(host_ptrs[slot_of[t]]).to(dev) for t in store.node_types}
+        # capacity of a batch per slot: B times the largest graph (ids may repeat)
+        self.cap = [int(np.diff(p).max()) * self.B for p in host_ptrs]
+        items, self._bufs, self._what = [], [], []
+        for t in store.node_types:
+            for k, pk in store.node_attrs[t].items():
+                it = _lib.CollateItem(pk.data.data_ptr(), self._node_ptr_dev[t].data_ptr(), 0, pk.row_bytes, slot_of[t], 0, 0)
+                items.append(it)
+                self._bufs.append(torch.empty((max(self.cap[slot_of[t]], 1),) + pk.row_shape, dtype=pk.data.dtype, device=dev))
+                self._what.append(("node", t, k))
+        for e in store.edge_types:
+            src = store.edge_index[e]
+            it = _lib.CollateItem(src.data_ptr(), store.edge_ptr[e].data_ptr(), int(src.size(1)), 0, slot_of[e], slot_of[e[0]], slot_of[e[2]])
+            items.append(it)
+            self._bufs.append(torch.empty(2 * max(self.cap[slot_of[e]], 1), dtype=torch.int64, device=dev))
+            self._what.append(("edge", e, "edge_index"))
+            if e in store.edge_attr:
+                pk = store.edge_attr[e]
+                items.append(_lib.CollateItem(pk.data.data_ptr(), store.edge_ptr[e].data_ptr(), 0, pk.row_bytes, slot_of[e], 0, 0))
+                self._bufs.append(torch.empty((max(self.cap[slot_of[e]], 1),) + pk.row_shape, dtype=pk.data.dtype, device=dev))
+                self._what.append(("edge", e, "edge_attr"))
+        n_items = len(items)
+        self._items = (_lib.CollateItem * n_items)(*items)
+        self._slot_ptr = (C.c_void_p * len(slots))(*[p.ctypes.data for p in host_ptrs])
+        h = C.c_void_p()
+        _lib.check(lib.hmp_collator_create(len(slots), self._slot_ptr, store.n_graphs, n_items, self._items, C.byref(h)))
+        self._h = h
+        self._dst = (C.c_void_p * n_items)(*[b.data_ptr() for b in self._bufs])
+        self._caps = (C.c_int64 * n_items)(*[self.cap[it.slot] for it in items])
+        self._totals = (C.c_int64 * len(slots))()
+        self._slots, self._slot_of = slots, slot_of
+        # ---- the executor's descriptor, filled once; per batch only the counts change
+        from .engine import _BatchHolder
+
+        nat = net.native() if hasattr(net, "native") else net
+        self.nat = nat
+        hd = _BatchHolder()
+        buf_of = {w: b for w, b in zip(self._what, self._bufs)}
+        self._node_slot, self._edge_slot = [], []
+        for i, t in enumerate(nat.node_types):
+            if t not in slot_of:
+                raise _lib.HydraMPError(f"the store holds no node type '{t}'")
+            self._node_slot.append(slot_of[t])
+            if nat.in_dims.get(t, 0) > 0:
+                x = buf_of[("node", t, "x")]
+                if x.dtype != torch.float32 or x.size(1) != nat.in_dims[t]:
+                    raise _lib.HydraMPError(f"store features of '{t}' are {tuple(x.shape[1:])} {x.dtype}, model expects {nat.in_dims[t]} float32")
+                hd.c.d_x[i] = x.data_ptr()
+                hd.c.ldx[i] = x.size(1)
+        for i, e in enumerate(nat.edge_types):
+            if e not in slot_of:
+                raise _lib.HydraMPError(f"the store holds no edge type {e}")
+            self._edge_slot.append(slot_of[e])
+            hd.c.d_edge_index[i] = buf_of[("edge", e, "edge_index")].data_ptr()
+            if nat.edge_dims.get(e, 0):
+                hd.c.d_edge_attr[i] = buf_of[("edge", e, "edge_attr")].data_ptr()
+        lab = buf_of[("node", label_type, label_key)]
+        if lab.dtype != torch.int64:
+            raise _lib.HydraMPError("labels in the store must be int64")
+        hd.c.d_labels = lab.data_ptr()
+        hd.keep = list(self._bufs)
+        hd.n_nodes = [0] * len(nat.node_types)
+        hd.n_edges = [0] * len(nat.edge_types)
+        out_type = nat.pool_edge_type[2] if nat.pool_edge_type is not None else nat.readout
+        if out_type != label_type:
+            raise _lib.HydraMPError(f"labels of '{label_type}' for a model that reads out '{out_type}'")
+        self._out_slot = slot_of[out_type]
+        self.holder = hd
+        self.label_buf = lab
+        # workspace sized once for the largest batch this stream can produce
+        cap_h = _BatchHolder()
+        cap_h.n_nodes = [self.cap[s] for s in self._node_slot]
+        cap_h.n_edges = [self.cap[s] for s in self._edge_slot]
+        flat = nat.flat_params()
+        with torch.cuda.device(flat.device):
+            nat._ensure_workspace(cap_h, flat.device)
+
+    def next(self, ids) -> "object":
+        """collate graphs ``ids`` (len == batch_size or fewer) into the stream's buffers; returns the descriptor for TrainStep.run"""
+        sel = np.ascontiguousarray(ids, dtype=np.int32)
+        B = int(sel.size)
+        if B > self.B:
+            raise _lib.HydraMPError(f"{B} graphs for a stream of batch size {self.B}")
+        _lib.check(self.store.lib.hmp_collator_run(self._h, sel.ctypes.data, B, self._dst, self._caps, self._totals, _lib.stream_ptr()))
+        hd, tot = self.holder, self._totals
+        for i, s in enumerate(self._node_slot):
+            v = tot[s]
+            hd.c.n_nodes[i] = v
+            hd.n_nodes[i] = v
+        for i, s in enumerate(self._edge_slot):
+            v = tot[s]
+            hd.c.n_edges[i] = v
+            hd.n_edges[i] = v
+        hd.c.n_out = tot[self._out_slot]
+        self.num_graphs = B
+        return hd
+
+    def data(self) -> HeteroData:
+        """the current batch as a HeteroData of VIEWS into the stream's buffers (valid until the next :meth:`next`)"""
+        out = HeteroData()
+        out.num_graphs = self.num_graphs
+        for (kind, key, name), buf in zip(self._what, self._bufs):
+            n = int(self._totals[self._slot_of[key]])
+            if name == "edge_index":
+                out[key].edge_index = buf[: 2 * n].view(2, n)
+            else:
+                setattr(out[key], name, buf[:n])
+        return out
+
+    def close(self):
+        if self._h is not None:
+            self.store.lib.hmp_collator_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _graphstore_stream(self, net, batch_size: int, label_type: str, label_key: str = "y") -> BatchStream:
+    return BatchStream(self, net, batch_size, label_type, label_key)
+
+
+GraphStore.stream = _graphstore_stream

@@ -319,6 +319,26 @@ int hmp_collate_edges(const int64_t* d_src, int64_t e_total, const int64_t* d_ed
                       const int64_t* d_dst_off, const int64_t* d_off_src, const int64_t* d_off_dst, int32_t B,
                       int64_t e_out, int64_t* d_dst, void* stream);
 
+/* One-launch form: the dataset description is fixed at creation, a batch costs ONE host call and ONE kernel.
+ *   slots   the distinct [G + 1] per-graph offset vectors (one per node type and per edge type; host copies are kept);
+ *   items   the output arrays: rows (row_bytes > 0: x / y / pos / edge_attr, positioned by `slot`) or an edge_index
+ *           (row_bytes == 0: int64 [2][src_total], positioned by `slot`, endpoints shifted by `slot_src` / `slot_dst`).
+ * hmp_collator_run: h_sel [B] graph ids (host), d_dst[i] / dst_capacity[i] per item (rows resp. edges), h_totals[slot] receives
+ * the batch's node / edge totals (the shapes of the outputs).  No allocation or synchronisation in the steady state. */
+typedef struct hmp_collate_item {
+  const void* d_src;
+  const int64_t* d_ptr;      /* device copy of the item's [G + 1] offsets */
+  int64_t src_total;         /* edges: E_total of the packed edge_index */
+  int64_t row_bytes;         /* rows: bytes per row (multiple of 4); edges: 0 */
+  int32_t slot, slot_src, slot_dst;
+} hmp_collate_item;
+typedef struct hmp_collator hmp_collator; /* opaque */
+int hmp_collator_create(int32_t n_slots, const int64_t* const* h_slot_ptr, int64_t n_graphs, int32_t n_items,
+                        const hmp_collate_item* items, hmp_collator** out);
+int hmp_collator_run(hmp_collator* c, const int32_t* h_sel, int32_t B, void* const* d_dst, const int64_t* dst_capacity,
+                     int64_t* h_totals, void* stream);
+void hmp_collator_destroy(hmp_collator* c);
+
 /* ---------------------------------------------------------------------------------------------
  * 9. Homogeneous GCN / GIN operators (csrc/homog.hip).  Replace [PyG] GCNConv.propagate + gcn_norm
  *    (models/utils.py:15-16), GINConv.propagate (models/utils.py:17-26) and BatchNorm (models/homogeneous_network.py:93-97).

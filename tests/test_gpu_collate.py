@@ -94,3 +94,58 @@ def test_collated_batches_drive_the_native_step_and_beat_host_collation():
     t_host = (time.perf_counter() - t0) / len(ids)
     print(f"collate per 32-graph batch: device store {1e3 * t_dev:.3f} ms, host collate + H2D {1e3 * t_host:.3f} ms")
     assert t_dev < t_host
+
+
+@pytest.mark.parametrize("batch_size,n_graphs,rel_pos", [(4, 12, False), (7, 9, True), (96, 120, False)])
+def test_batch_stream_one_launch_collation_is_bit_identical(batch_size, n_graphs, rel_pos):
+    """store.BatchStream (hmp_collator_run: one host call, one kernel, tables in the kernel's argument block for small batches
+    and through the pinned ring for large ones) == host collate, bit for bit, batch after batch in the same buffers."""
+    gs = mp3d_graphs(n_graphs, seed=21, rel_pos=rel_pos)
+    store = GraphStore(gs, DEV)
+    kw = dict(input_dim_dict={"objects": 303 if rel_pos else 306, "rooms": 3 if rel_pos else 6}, output_dim=26,
+              conv_block="GAT_edge" if rel_pos else "GraphSAGE", hidden_dim=16, num_layers=3, GAT_hidden_dims=[8, 8], GAT_heads=[2, 2, 2],
+              GAT_concats=[True, True, False], dropout=0.0)
+    torch.manual_seed(0)
+    net = HeterogeneousNetwork(**kw).to(DEV)
+    stream = store.stream(net, batch_size, "rooms")
+    rng = np.random.default_rng(1)
+    for it in range(12):  # > the ring depth of 8
+        ids = rng.choice(n_graphs, size=batch_size if it % 3 else max(batch_size // 2, 1), replace=True).tolist()
+        h = stream.next(ids)
+        got = stream.data()
+        ref = collate([gs[i] for i in ids])
+        for t in ref.node_types:
+            for k in ref[t].keys():
+                vb = getattr(ref[t], k)
+                if isinstance(vb, torch.Tensor) and k not in ("batch", "ptr"):
+                    assert torch.equal(getattr(got[t], k).cpu(), vb), (it, t, k)
+        for e in ref.edge_types:
+            assert torch.equal(got[e].edge_index.cpu(), ref[e].edge_index), (it, e)
+            if "edge_attr" in ref[e]:
+                assert torch.equal(got[e].edge_attr.cpu(), ref[e].edge_attr), (it, e)
+        assert int(h.c.n_out) == ref["rooms"].x.size(0)
+
+
+def test_batch_stream_drives_the_native_step_like_host_collated_batches():
+    """TrainStep.run(stream.next(ids)) == TrainStep(collate(...).to(device)) step for step: same losses, same parameters."""
+    gs = mp3d_graphs(40, seed=4)
+    store = GraphStore(gs, DEV)
+    kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, conv_block="GraphSAGE", hidden_dim=64, num_layers=3, dropout=0.25)
+    torch.manual_seed(0)
+    net_a = HeterogeneousNetwork(**kw).to(DEV)
+    torch.manual_seed(0)
+    net_b = HeterogeneousNetwork(**kw).to(DEV)
+    net_a.train(); net_b.train()
+    step_a = net_a.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=3, use_graph=False)
+    step_b = net_b.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=3, use_graph=False)
+    stream = store.stream(net_a, 8, "rooms")
+    rng = np.random.default_rng(2)
+    for it in range(10):
+        ids = rng.choice(40, size=8, replace=False).tolist()
+        step_a.run(stream.next(ids))
+        b = collate([gs[i] for i in ids]).to(DEV)
+        step_b(b, b["rooms"].y)
+        assert step_a.loss() == step_b.loss(), it
+    for (n, p), (_, q) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert torch.equal(p, q), n
+    assert step_a.steps_taken() == 10 and net_a.native().read_state()[1] == 0
