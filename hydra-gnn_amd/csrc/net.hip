@@ -719,14 +719,17 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
   return plan_launch(pb, &n->d_state->status, st);
 }
 
-// Small (launch-latency-bound) batches: the row-local GEMM that follows an aggregation (next layer's projection in the
+// Small (launch-latency-bound) batches (<= 65 536 nodes): the row-local GEMM that follows an aggregation (next layer's projection in the
 // forward pass, the input gradient in the backward pass) runs inside the aggregation kernel on 16-row tiles.  Large
 // batches keep the stand-alone 64x64-tile GEMM (16-row tiles would re-read the weights from L2 once per 16 rows).
 inline bool fuse_small(const hmp_net* n, const hmp_batch* b) {
   if (n->fuse_mode >= 0) return n->fuse_mode == 1;
   int64_t total = 0;
   for (int t = 0; t < n->T; ++t) total += b->n_nodes[t];
-  return total <= 16384;
+  // measured crossover on MI355X (tools/fuse_sweep.py, profiles/r02_fuse_sweep.json: config-2 network, batch 32 .. 2048):
+  // the small-batch sequence wins up to ~46 000 nodes (batch 512: 0.578 vs 0.586 ms) and loses from ~95 000 on
+  // (batch 1024: 1.085 vs 1.016 ms) -- 16-row tiles re-read the stacked weights once per 16 rows
+  return total <= 65536;
 }
 
 inline bool is_input(const hmp_net* n, int l, int t) { return l == 0 || (l == 1 && n->pass0[t]); }

@@ -432,3 +432,28 @@ def test_bf16_mode_htree_many_edge_types():
     assert float((out - ref).abs().max() / ref.abs().max()) < 3e-2
     for k, gr in gref.items():
         assert float((gout[k] - gr).norm() / (gr.norm() + 1e-20)) < 0.1, k
+
+
+def test_standalone_sequence_at_the_reference_batch_scale_matches_the_oracle(monkeypatch):
+    """config/mp3d/*.yaml train with batch_size 2048 (~190 000 nodes): far above the small-batch threshold, i.e. the stand-alone
+    launch sequence (grouped fp32 MFMA GEMMs + one-row-group aggregation, hidden 64).  At 512 graphs (46 000 nodes, a size the
+    float64 oracle holds) with that sequence pinned: logits, loss and every gradient at the north_star tolerance."""
+    monkeypatch.setenv("HMP_FUSE", "0")
+    ora, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork, seed=4)
+    batch = workloads.config2_batch(512)
+    o64 = copy.deepcopy(ora).double().eval()
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    y = batch["rooms"].y
+    pred_ref = o64(b64)
+    loss_ref = o64.loss(pred_ref, y, y != 25)
+    loss_ref.backward()
+    pred, loss, grads = run_fwd_bwd(net, batch, "rooms")
+    torch.testing.assert_close(pred.cpu().double(), pred_ref.detach(), atol=ATOL, rtol=RTOL)
+    torch.testing.assert_close(loss.cpu().double(), loss_ref.detach(), atol=ATOL, rtol=RTOL)
+    for name, p in o64.named_parameters():
+        if p.grad is not None:
+            # sums over 46 000 nodes in fp32: 1e-5 relative + 1e-5 of the tensor's scale
+            scale = max(float(p.grad.abs().max()), 1.0)
+            torch.testing.assert_close(grads[name].cpu().double(), p.grad, atol=ATOL * scale, rtol=RTOL, msg=lambda m: f"{name}: {m}")
