@@ -130,9 +130,12 @@ def make_workload(args, rank):
 # ------------------------------------------------------------------------------------------------------------
 # algorithmic (compulsory) traffic / flops of one training step, per kernel family
 # ------------------------------------------------------------------------------------------------------------
-def step_costs(net, holder, fused, root_in_place=False):
-    """Algorithmic (compulsory) bytes / flops of ONE step per kernel class, from the shapes of this batch (fp32 = 4 bytes;
-    formulas: DESIGN.md section 5).  `fused` = the small-batch launch sequence ran (front kernel,
+def step_costs(net, holder, fused, root_in_place=False, bf16_storage=False):
+    """Algorithmic (compulsory) bytes / flops of ONE step per kernel class, from the shapes of this batch (formulas: DESIGN.md
+    section 5), at the TRUE element size of every tensor: fp32 = 4 bytes everywhere except, with
+    `bf16_storage` (config 5 in bf16 mode), the tensors the engine stores as bf16 -- the projected rows Z and their gradient
+    dZ of a 256-wide layer, the hidden activations H and the input gradients G (2 bytes); features, weights, logits, the last
+    layer's narrow Z / dZ and the split-K slabs stay fp32.  `fused` = the small-batch launch sequence ran (front kernel,
     projections / input gradients inside the aggregation kernels): the GEMM terms are then charged to the kernels that
     execute them."""
     from hydra_gnn_amd._lib import CONV_GAT
@@ -151,6 +154,14 @@ def step_costs(net, holder, fused, root_in_place=False):
         cost[k]["flops"] += fl
 
     L = len(net.layers)
+
+    def wide(l):  # layer l's outputs are 256 wide: its Z / dZ / output H / the gradient G of that output are bf16-stored
+        return bf16_storage and all(al4(w) == 256 for w in net.layers[l].out_dims.values() if w)
+
+    zs = [2.0 if wide(l) else 4.0 for l in range(L)]                           # Z[l], dZ[l]
+    hin = [4.0] + [2.0 if wide(l - 1) else 4.0 for l in range(1, L)]           # H[l] as read by layer l (l = 0: the features)
+    hout = [2.0 if (wide(l) and l < L - 1) else 4.0 for l in range(L)]         # H[l + 1] as written by layer l
+    gin = [2.0 if (wide(l) and l < L - 1) else 4.0 for l in range(L)]          # gradient of layer l's output as read by its backward
     n_params = float(net.n_active)
     E_all = float(sum(holder.n_edges))
     N_all = float(sum(holder.n_nodes))
@@ -186,7 +197,7 @@ def step_costs(net, holder, fused, root_in_place=False):
             if nc == 0:
                 continue
             N, F = nn_[s], dims[l][s]
-            add(proj_cls, 4.0 * ((N * F if proj_cls != "agg_fwd" else 0) + nc * F + N * nc), 2.0 * N * F * nc)
+            add(proj_cls, (hin[l] * N * F if proj_cls != "agg_fwd" else 0) + 4.0 * nc * F + zs[l] * N * nc, 2.0 * N * F * nc)
         if proj_cls == "gemm_fwd":
             cost["gemm_fwd"]["launches"] += 1
         if gat:
@@ -206,19 +217,19 @@ def step_costs(net, holder, fused, root_in_place=False):
             # fused aggregation: indices + each projected source segment once + root + out
             for t in dsts:
                 Fo = al4(layer.out_dims[t])
-                b = 4.0 * nn_[t] * Fo * 2  # root read + out write
+                b = (zs[l] + hout[l]) * nn_[t] * Fo  # root read + out write
                 for c in live:
                     if c.edge_type[2] != t:
                         continue
-                    b += 4.0 * (nn_[t] + 1) + 4.0 * ne[c.edge_type] + 4.0 * nn_[c.edge_type[0]] * Fo
+                    b += 4.0 * (nn_[t] + 1) + 4.0 * ne[c.edge_type] + zs[l] * nn_[c.edge_type[0]] * Fo
                 add("agg_fwd", b, sum(ne[c.edge_type] * Fo for c in live if c.edge_type[2] == t))
             cost["agg_fwd"]["launches"] += 1
             # backward: transposed aggregation (same compulsory traffic as forward, mirrored)
-            add("agg_bwd", sum(4.0 * (nn_[c.edge_type[0]] + 1) + 8.0 * ne[c.edge_type] + 4.0 * nn_[c.edge_type[2]] * al4(c.f_out)
-                               + 4.0 * nn_[c.edge_type[0]] * al4(c.f_out) for c in live)
+            add("agg_bwd", sum(4.0 * (nn_[c.edge_type[0]] + 1) + 8.0 * ne[c.edge_type] + gin[l] * nn_[c.edge_type[2]] * al4(c.f_out)
+                               + zs[l] * nn_[c.edge_type[0]] * al4(c.f_out) for c in live)
                 # root block of dZ = copy of the output gradient; bf16 mode at 10^6 rows: read in place by the GEMMs, no copy
                 + (0.0 if (root_in_place and l < L - 1 and all(al4(layer.out_dims[t]) == 256 for t in dsts))
-                   else sum(8.0 * nn_[t] * al4(layer.out_dims[t]) for t in dsts)),
+                   else sum((gin[l] + zs[l]) * nn_[t] * al4(layer.out_dims[t]) for t in dsts)),
                 sum(2.0 * ne[c.edge_type] * al4(c.f_out) for c in live))
             cost["agg_bwd"]["launches"] += 1
         # weight gradient dWp = dZ^T [H | 1]  and (l > 0) input gradient dH = dZ * Wp
@@ -227,9 +238,10 @@ def step_costs(net, holder, fused, root_in_place=False):
             if nc == 0:
                 continue
             N, F = nn_[s], dims[l][s]
-            add("gemm_bwd", 4.0 * (N * nc + N * F + nc * (F + 1)), 2.0 * N * (F + 1) * nc)
+            add("gemm_bwd", zs[l] * N * nc + hin[l] * N * F + 4.0 * nc * (F + 1), 2.0 * N * (F + 1) * nc)
             if l > 0:
-                add(dx_cls, 4.0 * ((N * nc if dx_cls == "gemm_bwd" else 0) + nc * F + 2 * N * F), 2.0 * N * F * nc)
+                # input gradient: dZ (again), the weights, the activation mask (H[l]) and the gradient G[l] it writes
+                add(dx_cls, (zs[l] * N * nc if dx_cls == "gemm_bwd" else 0) + 4.0 * nc * F + hin[l] * N * F + gin[l - 1] * N * F, 2.0 * N * F * nc)
         if l > 0 and dx_cls == "gemm_bwd":
             cost["gemm_bwd"]["launches"] += 1
     cost["gemm_bwd"]["launches"] += 1 if fused else L  # weight gradients: one merged launch when fused
@@ -524,7 +536,8 @@ def main():
         scopes_per_step = sum(v[1] for v in per.values()) / float(prof_steps)
         scopes_ms = sum(v[0] for v in per.values()) / float(prof_steps)
         event_overhead_us = max(0.0, 1e3 * (scopes_ms - out["ms_per_step"]) / max(scopes_per_step, 1.0))
-        cost = step_costs(nat, prof_step._holder, fused, root_in_place=(args.config == 5 and args.precision == "bf16" and os.environ.get("HMP_ROOTCOPY") != "1" and os.environ.get("HMP_Z16") != "0"))
+        b16s = args.config == 5 and args.precision == "bf16" and os.environ.get("HMP_Z16") != "0"
+        cost = step_costs(nat, prof_step._holder, fused, root_in_place=(b16s and os.environ.get("HMP_ROOTCOPY") != "1"), bf16_storage=b16s)
         fam = {
             "front": ("front_kernel (layer-0 projection tiles + plan parts + pack blocks, one launch)", *per["front"]),
             "gemm_fwd": ("gemm_kernel (fp32 MFMA 32x32x2, grouped, LDS-staged)", *per["gemm_fwd"]),
@@ -575,9 +588,8 @@ def main():
                                        "dependent memory round trips (cold L2 after each kernel boundary), see DESIGN.md section 6"
                                        % (sum(c["bytes"] for c in cost.values()) / 1e6)) if args.config != 5 else (
                 "bandwidth regime" if args.precision != "bf16" else
-                "bandwidth regime; algorithmic bytes are counted at 4 bytes per element, but in this mode the projected rows Z and "
-                "the input gradients G are stored as bf16, so `achieved` overstates the bandwidth of the aggregation / projection "
-                "kernels by their Z / G terms (up to ~1.6x for the aggregation)")
+                "bandwidth regime; algorithmic bytes at the true element sizes (bf16 Z / dZ / H / G of the 256-wide layers, "
+                "fp32 features, weights, logits)")
             out["roofline_all"] = table
             # HBM traffic of the dominant family from the committed PMC passes of this same command (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_summary.py)
@@ -585,13 +597,17 @@ def main():
 
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_cfg{args.config}.json")))
             if pmc:
-                key = {"front": "front_kernel", "gemm_fwd": "gemm_kernel", "gemm_bwd": "gemm_tn_direct_kernel" if fused else "gemm_kernel",
-                       "agg_fwd": "agg_proj_fwd_kernel" if fused else "agg_fwd_kernel", "agg_bwd": "agg_bwd_dx_kernel" if fused else "agg_bwd_kernel",
+                key = {"front": "front_kernel", "gemm_fwd": "gemm_", "gemm_bwd": "gemm_tn_direct_kernel" if fused else "gemm_",
+                       "agg_fwd": "agg_proj_fwd_kernel" if fused else "agg_fwd_", "agg_bwd": "agg_bwd_dx_kernel" if fused else "agg_bwd_",
                        "gat_fwd": "gat_fwd_kernel", "gat_bwd": "gat_bwd", "grad_reduce": "grad_reduce_kernel"}[dom]
-                ks = [v for k, v in json.load(open(pmc[-1]))["kernels"].items() if key in k]
-                nd = sum(v["dispatches"] for v in ks)
-                if nd:
-                    out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in ks) / nd)
+                kern = json.load(open(pmc[-1]))["kernels"]
+                ks = [v for k, v in kern.items() if key in k]
+                # a launch scope of the family may cover several kernels (config 5: sliding-window kernel + plain kernel): bytes
+                # of the whole family per step (steps of the counter run = dispatches of the once-per-step un-pack kernel),
+                # divided by the scopes per step
+                steps_pmc = max([v["dispatches"] for k, v in kern.items() if "grad_reduce_kernel" in k] or [0])
+                if ks and steps_pmc and d["scopes_per_step"]:
+                    out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in ks) / steps_pmc / d["scopes_per_step"])
                     out["roofline"]["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
 
     # ---- CPU baseline: the oracle (op-for-op PyG restatement) on the host cores, bounded sample -------------------------
