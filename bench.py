@@ -380,7 +380,18 @@ def main():
     comm = None
     use_native_comm = args.collective == "rccl" and args.dist_backend == "nccl" and (world > 1 or args.force_collective)
     if use_native_comm:
-        comm = parallel.NativeComm.from_process_group(dev) if world > 1 else parallel.NativeComm.single()
+        try:
+            comm = parallel.NativeComm.from_process_group(dev) if world > 1 else parallel.NativeComm.single()
+            ok = torch.ones(1, device=dev)
+        except Exception as e:  # RCCL could not be bound by the library on this box: the same collective through torch
+            print(f"bench.py[rank {rank}]: hmp_comm unavailable ({e}); falling back to torch.distributed all_reduce", file=sys.stderr)
+            comm = None
+            ok = torch.zeros(1, device=dev)
+        if world > 1:  # all ranks must take the same path
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and comm is not None:
+                comm.close()
+                comm = None
     step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=20250225, use_graph=args.graph,
                           process_group=True if ((world > 1 or args.force_collective) and comm is None) else None,
                           force_collective=args.force_collective, comm=comm)

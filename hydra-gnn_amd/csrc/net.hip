@@ -115,6 +115,7 @@ struct hmp_net {
 
   // last forward
   bool have_fwd = false;
+  bool plan_ok = false;  // the plan arrays hold the topology of the last batch (cleared by a workspace re-bind)
   hmp_batch batch;
   int training = 0;
   uint64_t seed = 0;
@@ -130,6 +131,7 @@ struct hmp_net {
   int compute_bf16 = 0;    // hmp_net_set_compute: large grouped GEMMs on the bf16 matrix pipe (fp32 storage and accumulation)
   int fuse_mode = -1;      // HMP_FUSE override (0 / 1), -1 = automatic: row-local GEMMs ride in the aggregation kernels
   bool fuse_now = false;   // decision for the current batch
+  bool reuse_plan = false; // this call: hmp_batch::plan_valid accepted
   // fused training step: labels for the cross entropy riding in the last aggregation, Adam riding in the gradient un-pack
   const int64_t* ce_labels = nullptr;
   int64_t ce_ignored = 0;
@@ -726,10 +728,18 @@ inline bool fuse_small(const hmp_net* n, const hmp_batch* b) {
   if (n->fuse_mode >= 0) return n->fuse_mode == 1;
   int64_t total = 0;
   for (int t = 0; t < n->T; ++t) total += b->n_nodes[t];
-  // measured crossover on MI355X (tools/fuse_sweep.py, profiles/r02_fuse_sweep.json: config-2 network, batch 32 .. 2048):
-  // the small-batch sequence wins up to ~46 000 nodes (batch 512: 0.578 vs 0.586 ms) and loses from ~95 000 on
-  // (batch 1024: 1.085 vs 1.016 ms) -- 16-row tiles re-read the stacked weights once per 16 rows
-  return total <= 65536;
+  // measured crossover on MI355X (tools/fuse_sweep.py, profiles/r02_fuse_sweep.json: config-2 network, hidden 64, batch 32 .. 2048):
+  // the small-batch sequence wins up to ~46 000 nodes (batch 512: 0.578 vs 0.586 ms) and loses from ~95 000 on (batch 1024:
+  // 1.085 vs 1.016 ms).  What it pays is the stacked weights re-read from L2 once per 16-row tile: that crossover holds for
+  // stacked operands of the hidden-64 class (<= 64 KB); wider layers keep round 1's 16 384 (config 4, hidden 128: fused
+  // 0.455 ms against 0.634 ms stand-alone at ~10 000 nodes; hidden 256 is the bf16 regime's territory above that).
+  int64_t wmax = 1;
+  for (int l = 1; l < n->L; ++l)
+    for (int t = 0; t < n->T; ++t) {
+      const int64_t wb = (int64_t)n->lay[l].ncols[t] * n->lay[l].ldw[t] * 4;
+      wmax = wb > wmax ? wb : wmax;
+    }
+  return total <= (wmax <= 65536 ? 65536 : 16384);
 }
 
 inline bool is_input(const hmp_net* n, int l, int t) { return l == 0 || (l == 1 && n->pass0[t]); }
@@ -830,6 +840,7 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
   fa.need_tpos = 0;
   fa.plan_rc = plan_small_fits_rc(pb) ? 1 : 0;
   fa.plan_blocks = plan_small_layout(pb, fa.part_start, fa.rows_per_part);
+  if (n->reuse_plan) fa.plan_blocks = 0;  // same topology as the previous call: no plan role in this launch
   fa.ws = n->ws_base;
   auto woff = [&](const void* p) -> uint32_t { return (uint32_t)((reinterpret_cast<const char*>(p) - n->ws_base) >> 2); };
   if (n->ws_bytes >= ((size_t)1 << 34)) return false;  // 32-bit word offsets
@@ -864,6 +875,14 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   n->fuse_now = fuse_small(n, b);
   memset(n->h16, 0, sizeof(n->h16));
+  n->reuse_plan = false;
+  if (b->plan_valid) {
+    HMP_CHECK_ARG(n->plan_ok, "batch: plan_valid without a plan from a previous call (first call, or the workspace was re-bound)");
+    for (int e = 0; e < n->ET; ++e)
+      HMP_CHECK_ARG(n->plan[e].n_edges == b->n_edges[e] && n->plan[e].n_src == b->n_nodes[S.edge_src[e]] && n->plan[e].n_dst == b->n_nodes[S.edge_dst[e]],
+                    "batch: plan_valid but edge type %d changed shape since the previous call", e);
+    n->reuse_plan = true;
+  }
   // Small batches, SAGE layer 0: projection (reading the stacked weights straight from the flat parameters), plan and pack
   // are roles of ONE launch (front.hip) -- the plan, which has to read whole edge lists through single CUs, hides behind
   // the projection tiles.
@@ -926,7 +945,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     }
     z_done = false;
     if (l == 0 && !front) {
-      HMP_TRY(run_plan(n, b, main_st));
+      if (!n->reuse_plan) HMP_TRY(run_plan(n, b, main_st));
       if (side != main_st) HMP_TRY(fork_to(n, side, main_st));  // join
       st = main_st;
     }
@@ -1028,6 +1047,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     HMP_TRY(hmp_segment_mean_fwd(n->H[n->L][rt], n->ld[n->L][rt], n->out_ld, n->plan[S.pool_edge_type], n->d_out, n->out_ld, st));
   }
   n->have_fwd = true;
+  n->plan_ok = true;
   return HMP_OK;
 }
 
@@ -1432,6 +1452,7 @@ extern "C" int hmp_net_bind_workspace(hmp_net* n, void* d_workspace, size_t byte
   HMP_TRY(build_gat_tables(n));
   n->bound = true;
   n->have_fwd = false;
+  n->plan_ok = false;
   return HMP_OK;
 }
 

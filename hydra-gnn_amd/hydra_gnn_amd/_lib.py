@@ -78,6 +78,7 @@ class Batch(C.Structure):
         ("d_edge_attr", C.c_void_p * MAX_EDGE_TYPES),
         ("n_out", C.c_int32),
         ("d_labels", C.c_void_p),
+        ("plan_valid", C.c_int32),
     ]
 
 

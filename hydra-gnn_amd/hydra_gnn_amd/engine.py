@@ -59,6 +59,7 @@ class _BatchHolder:
         self.keep: List[torch.Tensor] = []
         self.n_nodes: List[int] = []
         self.n_edges: List[int] = []
+        self.edge_tensors: List[torch.Tensor] = []
         # an input had to be copied (dtype / layout conversion): the descriptor points at a private copy, so it must not be
         # reused for a later step (in-place edits of the caller's tensor would be missed)
         self.converted = False
@@ -96,6 +97,7 @@ class NativeNet:
         self._lib = None
         self._fwd_token = 0
         self._compute_bf16 = False
+        self._plan_key = None  # identity of the edge lists whose plan the workspace holds (predict() reuses it across frames)
 
     def set_compute(self, precision: str) -> None:
         """'fp32' (default): every projection on the exact fp32 MFMA path.  'bf16': GEMM calls in the throughput-bound regime
@@ -276,6 +278,7 @@ class NativeNet:
                     ei = ei.to(torch.int64).contiguous()
                     h.converted = True
                 h.keep.append(ei)
+                h.edge_tensors.append(ei)
                 h.c.n_edges[i] = ei.size(1)
                 h.c.d_edge_index[i] = ei.data_ptr() if ei.size(1) > 0 else None
             else:
@@ -369,8 +372,13 @@ class NativeNet:
                 self._pred_done = torch.cuda.Event()
             out_p, ld = C.c_void_p(), C.c_int32()
             st = _lib.stream_ptr()
+            # consecutive frames with the SAME edge tensors (unchanged in place): the plan of the previous call is reused
+            # (bin/room_classification_server:273-299 re-infers on a graph whose topology did not change)
+            key = None if h.converted else (id(self._ws), tuple(h.n_nodes), tuple((t.data_ptr(), t._version, t.size(-1)) for t in h.edge_tensors))
+            h.c.plan_valid = 1 if (key is not None and key == self._plan_key) else 0
             _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), flat.data_ptr(), 0, 0, 0, C.byref(out_p), C.byref(ld), st))
             self._fwd_token += 1
+            self._plan_key = key
             if n > 0:
                 _lib.check(self._lib.hmp_argmax_rows(out_p.value, ld.value, n, int(n_classes), self._pred_dev.data_ptr(), st))
                 self._pred_host[:n].copy_(self._pred_dev[:n], non_blocking=True)
@@ -383,6 +391,7 @@ class NativeNet:
         _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), self._flat.data_ptr(), int(training), seed, rng_step,
                                              C.byref(out_p), C.byref(ld), _lib.stream_ptr()))
         self._fwd_token += 1
+        self._plan_key = None
         out = self._ws_view(out_p.value, int(h.c.n_out), ld.value).clone()
         if self.aux_readout is None:
             return out
@@ -560,6 +569,7 @@ class TrainStep:
         with torch.cuda.device(dev):
             net._ensure_workspace(h, dev)
             net._fwd_token += 1  # the step overwrites the activations of any earlier forward()
+            net._plan_key = None
             if not self.use_graph:
                 st = _lib.stream_ptr()
                 if self._world() == 1 and not self.force_collective:
@@ -632,6 +642,7 @@ class TrainStep:
         if self.use_graph:
             raise _lib.HydraMPError("TrainStep.run steps a NEW batch every call: create the step with use_graph=False")
         net._fwd_token += 1
+        net._plan_key = None
         self._batch_key = None
         self._holder = holder
         st = _lib.stream_ptr()

@@ -221,6 +221,9 @@ typedef struct hmp_batch {
   const float* d_edge_attr[HMP_MAX_EDGE_TYPES];    /* [E, edge_dim] or NULL */
   int32_t n_out;             /* rows of the output (== n_nodes[readout] unless pooled) */
   const int64_t* d_labels;   /* [n_out] int64, or NULL (forward only) */
+  int32_t plan_valid;        /* != 0: the caller vouches that every edge list equals the previous call's (same topology, e.g.
+                              * consecutive frames of the inference server, bin/room_classification_server:273-299): the CSR /
+                              * CSC plan in the workspace is reused instead of rebuilt.  Counts must match the previous call. */
 } hmp_batch;
 
 typedef struct hmp_train_args {

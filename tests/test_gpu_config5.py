@@ -147,6 +147,7 @@ def test_config5_fp32_mode_matches_the_float64_oracle(graph):
 
 def test_config5_bf16_mode_matches_the_bf16_contract_oracle(graph, monkeypatch):
     monkeypatch.setenv("HMP_BF16_ALL", "1")  # the 10^6-object regime's decisions at a size the oracle can hold
+    monkeypatch.setenv("HMP_FUSE", "0")      # ... incl. its launch sequence (stand-alone GEMMs: the ones that run in bf16)
     ora, net = build(seed=1)
     net.native().set_compute("bf16")
     g = graph.to(DEV)

@@ -2,7 +2,7 @@
 gradient un-pack) against the stand-alone kernels and against the oracle.
 
 HMP_FUSE=0 / 1 pins the executor to the stand-alone / fused launch sequence (read when the native net is created);
-unset = automatic (fused up to 16384 nodes per batch).  Both sequences must satisfy the oracle tolerance, and they must
+unset = automatic (fused up to 65536 nodes per batch at hidden 64, 16384 for wider layers).  Both sequences must satisfy the oracle tolerance, and they must
 agree with each other far inside it (they differ only in fp32 summation order of the projections).
 """
 import copy

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from hydra_gnn_amd import ops, workloads  # noqa: E402
-from hydra_gnn_amd.data import collate_homogeneous  # noqa: E402
+from hydra_gnn_amd.data import collate, collate_homogeneous  # noqa: E402
 from hydra_gnn_amd.models import (HeterogeneousNetwork, HeterogeneousNeuralTreeNetwork, HomogeneousNetwork)  # noqa: E402
 
 DEV = "cuda:0"
@@ -81,3 +81,37 @@ def test_predict_leaves_training_state_alone():
     net.predict(batch)
     with pytest.raises(_lib.HydraMPError):
         pred.sum().backward()
+
+
+def test_predict_reuses_the_plan_across_frames_with_unchanged_topology():
+    """Same edge tensors, new features (a frame whose objects moved but whose graph did not change): predict() skips the plan
+    build (hmp_batch.plan_valid) and returns what a full rebuild returns; any change of the edge tensors rebuilds."""
+    import copy as _copy
+
+    torch.manual_seed(3)
+    kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, conv_block="GraphSAGE", hidden_dim=64, num_layers=3, dropout=0.25)
+    net = HeterogeneousNetwork(**kw).to(DEV).eval()
+    ref = HeterogeneousNetwork(**kw).to(DEV).eval()
+    ref.load_state_dict(net.state_dict())
+    frame = collate([workloads.mp3d_like_graph(np.random.default_rng(8))]).to(DEV)
+    a0 = net.predict(frame).clone()
+    assert net.native()._plan_key is not None
+    for k in range(3):
+        frame["objects"].x = frame["objects"].x + 0.05 * torch.randn_like(frame["objects"].x)  # new features, same edge tensors
+        fresh = _copy.copy(frame)
+        got = net.predict(frame).clone()  # plan reused
+        want = ref.predict(collate([frame.to("cpu")]).to(DEV)).clone()  # new tensors: plan rebuilt
+        assert torch.equal(got, want), k
+    # an in-place edit of an edge list bumps its version: the plan is rebuilt and the answer follows
+    et = ("objects", "objects_to_objects", "objects")
+    ei = frame[et].edge_index
+    ei[:, 0] = ei[:, 1]
+    got = net.predict(frame).clone()
+    want = ref.predict(collate([frame.to("cpu")]).to(DEV)).clone()
+    assert torch.equal(got, want)
+    # a training step in between invalidates the reuse
+    step = net.train_step(lr=0.001, ignored_label=25, use_graph=False)
+    net.train(); step(frame, frame["rooms"].y); net.eval()
+    assert net.native()._plan_key is None
+    ref.load_state_dict(net.state_dict())
+    assert torch.equal(net.predict(frame), ref.predict(collate([frame.to("cpu")]).to(DEV)))
