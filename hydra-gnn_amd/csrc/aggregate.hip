@@ -18,6 +18,8 @@ namespace hmp {
 KT_DEFINE(agg)
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+constexpr int WIN_THREADS_CHAIN = 512;   // graph-local chain kernel: CHAIN_GROUPS groups of 256 threads (1024 threads would cap the
+constexpr int CHAIN_GROUPS = WIN_THREADS_CHAIN / 256;  // tile routines at 128 VGPRs: measured 1 201 spilled registers, 0.49 ms)
 
 // ----- row access helpers -----------------------------------------------------------------------
 // VEC = 4: 16-byte accesses (pointer and ld 16-byte aligned); VEC = 1: scalar fall-back for arbitrary ld.
@@ -472,18 +474,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // GS >= 32 (H-tree, hidden 128: ~1000 blocks of 16 rows): 4 waves per SIMD = 4 blocks per CU keeps the whole launch resident in
 // one round (measured 0.152 -> 0.140 ms over the 4 layers of config 4 despite 148 bytes of spill; the same bound made the
 // backward kernel slower and is not applied there)
+// One 16-row tile [row0, row0 + 16) of destination entry D, rows below row_end, by ONE group of 256 threads (tid = thread inside
+// the group) with its own LDS image Hs [256][17].  Every group of the workgroup must call this the same number of times: the
+// barrier between the aggregation and the projection is workgroup-wide (`valid` = false: a group without a tile only joins it).
 template <int GS>
-__global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
+__device__ __forceinline__ void agg_proj_tile(const AggArgs& a, const AggDst& D, int row0, int row_end, bool valid, float* Hs) {
   constexpr int TM = 16, LDH = 17;
   constexpr int RPP = 256 / GS;            // rows aggregated per pass
   constexpr int NP = TM / RPP;             // passes (GS = 16: 1, 32: 2, 64: 4)
-  __shared__ float Hs[256 * LDH];
-  int ti = 0;
-  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
-  const AggDst& D = a.d[ti];
-  const int row0 = ((int)blockIdx.x - D.block_start) * TM;
-  const int c0 = (threadIdx.x % GS) * 4;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tid = threadIdx.x & 255;
+  const int c0 = (tid % GS) * 4;
+  const int lane = threadIdx.x & 63, w = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
   KT(0);
   // The weights of the projection do not depend on the aggregation: request the first PT column tiles of this wave (first
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(con
   // overlaps the three round trips of the gather instead of following them.
   constexpr int PT = 3;
   float4 pre[PT][4];
-  const int n_ct = D.pw ? (D.pncols + 15) >> 4 : 0;
-  if (D.pw) {  // block-uniform
+  const int n_ct = (valid && D.pw) ? (D.pncols + 15) >> 4 : 0;
+  if (valid && D.pw) {  // group-uniform
 #pragma unroll
     for (int it = 0; it < PT; ++it) {
       const int col = min((w + 4 * it) * 16 + n, D.pncols - 1);  // clamped: tiles past n_ct are never used
@@ -501,20 +502,22 @@ __global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(con
       for (int u = 0; u < 4; ++u) pre[it][u] = *reinterpret_cast<const float4*>(wrow + min(16 * u, D.pK - 16) + 4 * kq);
     }
   }
+  if (valid) {
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int m = p * RPP + threadIdx.x / GS;
-    const int row = row0 + m;
-    Acc<4> tot[1];
-    tot[0].zero();
-    if (row < D.n_rows) agg_row<GS, 1>(D, a.mean, row, c0, tot);
-    if (c0 < D.pK) {
+    for (int p = 0; p < NP; ++p) {
+      const int m = p * RPP + tid / GS;
+      const int row = row0 + m;
+      Acc<4> tot[1];
+      tot[0].zero();
+      if (row < row_end) agg_row<GS, 1>(D, a.mean, row, c0, tot);
+      if (c0 < D.pK) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) Hs[(c0 + i) * LDH + m] = (c0 < D.F && row < D.n_rows) ? tot[0].at(i) : 0.f;
+        for (int i = 0; i < 4; ++i) Hs[(c0 + i) * LDH + m] = (c0 < D.F && row < row_end) ? tot[0].at(i) : 0.f;
+      }
     }
   }
-  if (D.pw == nullptr) return;  // block-uniform: this node type is not read by the next layer
   __syncthreads();
+  if (!valid || D.pw == nullptr) return;  // group-uniform: no tile / this node type is not read by the next layer
   KT(1);
   // one 16-column tile: bv0 = prefetched weights of the first k trip (null: load them here)
   auto tile = [&](int ct, const float4* bv0) {
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(con
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + kq * 4 + r;
-        if (row < D.n_rows) D.pz[(int64_t)row * D.pldz + col] = acc[r];
+        if (row < row_end) D.pz[(int64_t)row * D.pldz + col] = acc[r];
       }
     }
   };
@@ -551,6 +554,15 @@ __global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(con
     if (w + 4 * it < n_ct) tile(w + 4 * it, pre[it]);
   for (int ct = w + 4 * PT; ct < n_ct; ct += 4) tile(ct, nullptr);
   KT(2);
+}
+
+template <int GS>
+__global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
+  __shared__ float Hs[256 * 17];
+  int ti = 0;
+  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
+  const AggDst& D = a.d[ti];
+  agg_proj_tile<GS>(a, D, ((int)blockIdx.x - D.block_start) * 16, D.n_rows, true, Hs);
 }
 
 // fixed-order sum of the per-row {loss, valid} pairs -> {loss_sum, count}; run by ONE block (256 threads)
@@ -575,23 +587,10 @@ __device__ __forceinline__ void finalize_loss(const float* __restrict__ row_lv, 
 // dz[s][j, seg_e] = sum_{k in out_e(j)} g'[dst_k] / deg(dst_k);   dz[s][j, root] = g'[s][j]
 // GB: the gradient rows (TAggOut::g, TAggSrc::groot) hold bf16 elements (bf16 compute mode at 10^6 rows, see load_z);
 // DZB: so does the output dz (read back by the bf16 GEMMs as their A operand)
+// one row of source entry S by its row group of GS lanes (c0 = first column of the lane); `row` must be < S.n_rows
 template <int GS, int NV, bool GB = false, bool DZB = false>
-__global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
+__device__ __forceinline__ void agg_bwd_row(const TAggArgs& a, const TAggSrc& S, int row, int c0) {
   constexpr int VEC = 4;
-  if ((int)blockIdx.x == a.total_blocks) {  // the extra block (only launched when fin_row_lv is set)
-    finalize_loss(a.fin_row_lv, a.fin_rows, a.fin_out2, a.fin_state);
-    return;
-  }
-  int si = 0;
-  while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
-  const TAggSrc& S = a.s[si];
-  const int rpb = 256 / GS;
-  int local = blockIdx.x - S.block_start;
-  if (a.xcd) local = (local & 7) * ((cdiv_dev(S.n_rows, rpb) + 7) >> 3) + (local >> 3);  // see agg_fwd_kernel
-  int row = local * rpb + threadIdx.x / GS;
-  if (GS == 64) row = __builtin_amdgcn_readfirstlane(row);  // wave-uniform, see agg_fwd_kernel
-  if (row >= S.n_rows) return;
-  const int c0 = (threadIdx.x % GS) * VEC;
   int rb[AGG_MAX_IN], re[AGG_MAX_IN];
 #pragma unroll
   for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
@@ -711,36 +710,48 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   }
 }
 
-// ----- transposed aggregation of layer l FUSED with its input-gradient GEMM ------------------------------------------
-// dH[l][s] = (dZ[l][s] * Wp[l][s]) . act'(H[l][s]) is row-local, so the block that has just gathered 16 rows of dZ keeps
-// them in LDS ([k][row] image, LD 17) and multiplies them on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): one
-// kernel and one hand-off of dZ through L2 less per layer.  dZ is still written to HBM (the weight-gradient GEMM reads it).
-// Wp [ncols][ldw] is read from L2: lane (n, kq) loads Wp[kb + kq][n0 + n] (16 lanes = one 64-byte segment).
-template <int GS>
-__global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
-  constexpr int TM = 16, LDH = 17, VEC = 4;
-  constexpr int RPP = 256 / GS;  // rows gathered per pass
-  constexpr int NP = TM / RPP;   // passes (GS = 16: 1, 32: 2, 64: 4)
-  extern __shared__ float Hs[];  // [ncols][LDH]
-  if ((int)blockIdx.x == a.total_blocks) {
+template <int GS, int NV, bool GB = false, bool DZB = false>
+__global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
+  if ((int)blockIdx.x == a.total_blocks) {  // the extra block (only launched when fin_row_lv is set)
     finalize_loss(a.fin_row_lv, a.fin_rows, a.fin_out2, a.fin_state);
     return;
   }
   int si = 0;
   while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
   const TAggSrc& S = a.s[si];
-  const int row0 = ((int)blockIdx.x - S.block_start) * TM;
-  const int c0 = (threadIdx.x % GS) * VEC;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rpb = 256 / GS;
+  int local = blockIdx.x - S.block_start;
+  if (a.xcd) local = (local & 7) * ((cdiv_dev(S.n_rows, rpb) + 7) >> 3) + (local >> 3);  // see agg_fwd_kernel
+  int row = local * rpb + threadIdx.x / GS;
+  if (GS == 64) row = __builtin_amdgcn_readfirstlane(row);  // wave-uniform, see agg_fwd_kernel
+  if (row >= S.n_rows) return;
+  agg_bwd_row<GS, NV, GB, DZB>(a, S, row, (int)(threadIdx.x % GS) * 4);
+}
+
+// ----- transposed aggregation of layer l FUSED with its input-gradient GEMM ------------------------------------------
+// dH[l][s] = (dZ[l][s] * Wp[l][s]) . act'(H[l][s]) is row-local, so the block that has just gathered 16 rows of dZ keeps
+// them in LDS ([k][row] image, LD 17) and multiplies them on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): one
+// kernel and one hand-off of dZ through L2 less per layer.  dZ is still written to HBM (the weight-gradient GEMM reads it).
+// Wp [ncols][ldw] is read from L2: lane (n, kq) loads Wp[kb + kq][n0 + n] (16 lanes = one 64-byte segment).
+// one 16-row tile of source entry S by one group of 256 threads, LDS image Hs [ncols][17]; see agg_proj_tile for `valid`
+template <int GS>
+__device__ __forceinline__ void agg_bwd_dx_tile(const TAggArgs& a, const TAggSrc& S, int row0, int row_end, bool valid, float* Hs) {
+  constexpr int TM = 16, LDH = 17, VEC = 4;
+  constexpr int RPP = 256 / GS;  // rows gathered per pass
+  constexpr int NP = TM / RPP;   // passes (GS = 16: 1, 32: 2, 64: 4)
+  const int tid = threadIdx.x & 255;
+  const int c0 = (tid % GS) * VEC;
+  const int lane = threadIdx.x & 63, w = tid >> 6;
   const int nn = lane & 15, kq = lane >> 4;
   const int K = S.ncols;
   KT(8);
   constexpr int WB = 48;
+  if (valid) {
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    const int m = p * RPP + threadIdx.x / GS;
+    const int m = p * RPP + tid / GS;
     const int row = row0 + m;
-    const bool live = row < S.n_rows;
+    const bool live = row < row_end;
     int rb[AGG_MAX_IN], re[AGG_MAX_IN];
 #pragma unroll
     for (int oi = 0; oi < AGG_MAX_IN; ++oi) {
@@ -848,8 +859,9 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
       for (int i = 0; i < 4; ++i) Hs[(S.roff + c0 + i) * LDH + m] = v.at(i);
     }
   }
-  if (S.xw == nullptr) return;  // block-uniform
+  }
   __syncthreads();
+  if (!valid || S.xw == nullptr) return;  // group-uniform
   KT(9);
   const int n_ct = (S.xN + 15) >> 4;
   for (int ct = w; ct < n_ct; ct += 4) {
@@ -862,7 +874,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     if (S.xh) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        hv[r] = S.xh[(int64_t)min(row0 + kq * 4 + r, S.n_rows - 1) * S.xldh + min(col, S.xN - 1)];
+        hv[r] = S.xh[(int64_t)min(row0 + kq * 4 + r, row_end - 1) * S.xldh + min(col, S.xN - 1)];
     }
     // 48 k-steps (192 stacked columns) per trip: the (clamped) weight loads are all in flight together, then the MFMA
     // chain runs -- one L2 round trip for the typical stacked width.  (Requesting them before the gather was measured
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + kq * 4 + r;
-        if (row >= S.n_rows) continue;
+        if (row >= row_end) continue;
         float v = acc[r];
         if (S.xh) {
           const float h = hv[r];
@@ -897,6 +909,170 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     }
   }
   KT(10);
+}
+
+template <int GS>
+__global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
+  extern __shared__ float Hs[];  // [ncols][17]
+  if ((int)blockIdx.x == a.total_blocks) {
+    finalize_loss(a.fin_row_lv, a.fin_rows, a.fin_out2, a.fin_state);
+    return;
+  }
+  int si = 0;
+  while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
+  const TAggSrc& S = a.s[si];
+  agg_bwd_dx_tile<GS>(a, S, ((int)blockIdx.x - S.block_start) * 16, S.n_rows, true, Hs);
+}
+
+// ----- graph-local chain: every launch between the front kernel and the weight-gradient GEMM, in ONE launch ------------------
+// A batch is a disjoint union of scene graphs: no edge crosses graphs, so from the first aggregation to the last transposed
+// aggregation a graph depends on nothing but itself.  One 1024-thread workgroup owns one graph for ALL of those phases
+// (aggregation + next projection per hidden layer, last aggregation + masked cross entropy, transposed aggregation +
+// input-gradient GEMM per layer): what were 2L launches with a cold L2 behind every boundary become phases separated by a
+// workgroup barrier, their operands written moments earlier by the same CU.  The phases ARE the tile / row routines of the
+// kernels above (four groups of 256 threads take the graph's 16-row tiles in turn), so results are bit-identical to the
+// multi-launch sequence (HMP_CHAIN=0).  The last workgroup to finish (an atomic ticket, no spinning) sums the per-row losses.
+// locate tile k of a phase: entries in order, ceil(rows / 16) tiles each
+template <class ARGS, class ENTRY>
+__device__ __forceinline__ bool chain_tile(const ChainArgs& A, const ARGS& a, const ENTRY* ents, const int* types, int g, int k, int& ei,
+                                           int& row0, int& row_end) {
+  for (int i = 0; i < a.n; ++i) {
+    const int64_t* pt = A.ptr[types[i]];
+    const int r0 = (int)pt[g], r1 = (int)pt[g + 1];
+    const int nt = (r1 - r0 + 15) >> 4;
+    if (k < nt) { ei = i; row0 = r0 + 16 * k; row_end = r1; return true; }
+    k -= nt;
+  }
+  ei = 0; row0 = 0; row_end = 0;
+  return false;
+}
+template <class ARGS>
+__device__ __forceinline__ int chain_tiles(const ChainArgs& A, const ARGS& a, const int* types, int g) {
+  int n = 0;
+  for (int i = 0; i < a.n; ++i) {
+    const int64_t* pt = A.ptr[types[i]];
+    n += ((int)pt[g + 1] - (int)pt[g] + 15) >> 4;
+  }
+  return n;
+}
+
+template <int GS>
+__device__ __forceinline__ void chain_ce_rows(const ChainArgs& A, const AggArgs& a, const int* types, int g) {
+  for (int i = 0; i < a.n; ++i) {
+    const AggDst& D = a.d[i];
+    const int64_t* pt = A.ptr[types[i]];
+    const int r0 = (int)pt[g], r1 = (int)pt[g + 1];
+    const int c0 = (threadIdx.x % GS) * 4;
+    for (int row = r0 + (int)threadIdx.x / GS; row < r1; row += WIN_THREADS_CHAIN / GS) {
+      Acc<4> tot[1];
+      int64_t y = 0;
+      if (D.ce_labels) y = D.ce_labels[row];
+      agg_row<GS, 1>(D, a.mean, row, c0, tot);
+      if (D.ce_labels) ce_rowgroup<GS>(D, a.state, row, c0, tot[0], y);
+    }
+  }
+}
+template <int GS>
+__device__ __forceinline__ void chain_bwd_rows(const ChainArgs& A, const TAggArgs& a, const int* types, int g) {
+  for (int i = 0; i < a.n; ++i) {
+    const TAggSrc& S = a.s[i];
+    const int64_t* pt = A.ptr[types[i]];
+    const int r0 = (int)pt[g], r1 = (int)pt[g + 1];
+    const int c0 = (threadIdx.x % GS) * 4;
+    for (int row = r0 + (int)threadIdx.x / GS; row < r1; row += WIN_THREADS_CHAIN / GS) agg_bwd_row<GS, 1>(a, S, row, c0);
+  }
+}
+
+template <int GS>
+__global__ __launch_bounds__(WIN_THREADS_CHAIN) void chain_kernel(const ChainArgs* __restrict__ Ap, int n_graphs, int fin_rows) {
+  extern __shared__ __attribute__((aligned(16))) float clds[];
+  __shared__ int s_last;
+  // the argument block (28 KB: the descriptors of every phase) is copied into LDS once -- read through the global pointer, every
+  // descriptor field an aggregation routine touches would be a dependent memory round trip of its own (measured: 0.51 ms
+  // for what five launches did in 0.05 ms); in the multi-launch kernels these fields sit in scalar registers
+  constexpr int ARG_F = (int)((sizeof(ChainArgs) + 15) / 16) * 4;  // floats
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(Ap);
+    uint4* dst = reinterpret_cast<uint4*>(clds);
+    for (int i = threadIdx.x; i < ARG_F / 4; i += WIN_THREADS_CHAIN) dst[i] = src[i];
+  }
+  __syncthreads();
+  const ChainArgs& A = *reinterpret_cast<const ChainArgs*>(clds);
+  const int g = blockIdx.x;
+  const int grp = threadIdx.x >> 8;
+  float* Hs = clds + ARG_F + (size_t)grp * A.lds_stride;
+  const int L = A.L;
+  // ---- forward
+  for (int l = 0; l < L; ++l) {
+    const AggArgs& a = A.fwd[l];
+    if (l < L - 1) {
+      const int T = chain_tiles(A, a, A.fwd_type[l], g);
+      for (int k0 = 0; k0 < T; k0 += CHAIN_GROUPS) {
+        int ei, row0, row_end;
+        const bool valid = chain_tile(A, a, a.d, A.fwd_type[l], g, k0 + grp, ei, row0, row_end);
+        agg_proj_tile<GS>(a, a.d[ei], row0, row_end, valid, Hs);
+        __syncthreads();  // the group's LDS image is rewritten by its next tile
+      }
+    } else {
+      if (A.gs_last == 8) chain_ce_rows<8>(A, a, A.fwd_type[l], g);
+      else if (A.gs_last == 16) chain_ce_rows<16>(A, a, A.fwd_type[l], g);
+      else chain_ce_rows<32>(A, a, A.fwd_type[l], g);
+    }
+    __syncthreads();  // phase boundary: this graph's rows of the layer are complete and visible to the whole workgroup
+  }
+  // ---- backward
+  for (int l = L - 1; l >= 0; --l) {
+    const TAggArgs& a = A.bwd[l];
+    if (l > 0) {
+      const int T = chain_tiles(A, a, A.bwd_type[l], g);
+      for (int k0 = 0; k0 < T; k0 += CHAIN_GROUPS) {
+        int ei, row0, row_end;
+        const bool valid = chain_tile(A, a, a.s, A.bwd_type[l], g, k0 + grp, ei, row0, row_end);
+        agg_bwd_dx_tile<GS>(a, a.s[ei], row0, row_end, valid, Hs);
+        __syncthreads();
+      }
+    } else {
+      if (A.gs_first == 8) chain_bwd_rows<8>(A, a, A.bwd_type[l], g);
+      else if (A.gs_first == 16) chain_bwd_rows<16>(A, a, A.bwd_type[l], g);
+      else chain_bwd_rows<32>(A, a, A.bwd_type[l], g);
+    }
+    __syncthreads();
+  }
+  // ---- the last workgroup to arrive sums the per-row {loss, valid} pairs of ALL graphs (fixed order: run-to-run identical)
+  if (A.fin_row_lv) {
+    if (threadIdx.x == 0) {
+      __threadfence();  // this workgroup's row_lv stores are out before the ticket
+      const unsigned t = atomicAdd(A.ticket, 1u);
+      s_last = (t == (unsigned)n_graphs - 1u) ? 1 : 0;
+      if (s_last) { *A.ticket = 0u; __threadfence(); }  // re-armed for the next step; acquire side of the hand-off
+    }
+    __syncthreads();
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // the summation order of finalize_loss (256 strided partial sums, then a tree): the same bits as the multi-launch path
+      float l = 0.f, v = 0.f;
+      const float* lv = A.fin_row_lv;
+      if (threadIdx.x < 256) {
+        for (int r = threadIdx.x; r < fin_rows; r += 256) {
+          l += __hip_atomic_load(lv + 2 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v += __hip_atomic_load(lv + 2 * r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      float* sl = clds + ARG_F;
+      float* sv = clds + ARG_F + 256;
+      if (threadIdx.x < 256) { sl[threadIdx.x] = l; sv[threadIdx.x] = v; }
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sv[threadIdx.x] += sv[threadIdx.x + o]; }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        A.fin_out2[0] = sl[0];
+        A.fin_out2[1] = sv[0];
+        if (A.fin_state) { A.fin_state->loss_sum = sl[0]; A.fin_state->count = sv[0]; }
+      }
+    }
+  }
 }
 
 // ----- LDS sliding-window aggregation for the 10^6-row regime (bf16 rows of 256 elements = 512 bytes) ------------------------
@@ -1400,6 +1576,21 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_bwd_win_kernel(const WinBwd a
     }
     __syncthreads();
   }
+}
+
+int chain_launch(const ChainArgs* d_args, int n_graphs, int fin_rows, int gs, size_t lds_bytes, hipStream_t st) {
+  lds_bytes += ((sizeof(ChainArgs) + 15) / 16) * 16;  // + the LDS copy of the argument block
+  HMP_CHECK_ARG(d_args && n_graphs > 0 && (gs == 16 || gs == 32) && lds_bytes <= 150 * 1024, "chain: bad launch (%d graphs, gs %d, %zu LDS bytes)", n_graphs, gs, lds_bytes);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_done = true;
+  }
+  if (gs == 16) hipLaunchKernelGGL((chain_kernel<16>), dim3(n_graphs), dim3(WIN_THREADS_CHAIN), lds_bytes, st, d_args, n_graphs, fin_rows);
+  else hipLaunchKernelGGL((chain_kernel<32>), dim3(n_graphs), dim3(WIN_THREADS_CHAIN), lds_bytes, st, d_args, n_graphs, fin_rows);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
 }
 
 // ----- dispatch ---------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ namespace hmp {
 
 constexpr int CB_MAX_ITEMS = 20;
 constexpr int CB_MAX_SLOTS = 12;
-constexpr int CB_INLINE_WORDS = 360;  // int64 words of per-batch tables carried by value in the kernel argument block (whole block < 4 KB)
+constexpr int CB_INLINE_WORDS = 356;  // int64 words of per-batch tables carried by value in the kernel argument block (whole block < 4 KB)
 
 struct CbItem {
   const uint32_t* src;    // rows: packed rows (4-byte units); edges: int64 edge_index [2][src_total] viewed as units
@@ -105,6 +105,8 @@ struct CbItem {
 struct CbArgs {
   int n_items, B, total_blocks, n_slots;
   const int64_t* tables;  // device tables (large batches), null: inline
+  int64_t* off_out;       // optional: the offset vectors are also written here, [n_slots][off_stride] (Batch.ptr of every slot)
+  int off_stride;
   CbItem item[CB_MAX_ITEMS];
   int64_t inl[CB_INLINE_WORDS];  // [n_slots][B + 1] offsets, then sel packed as int64
 };
@@ -121,6 +123,8 @@ __global__ __launch_bounds__(256) void collate_batch_kernel(const CbArgs a) {
   const int64_t* sel = tab + (int64_t)a.n_slots * (B + 1);
   const int nb = (ii + 1 < a.n_items ? a.item[ii + 1].block_start : a.total_blocks) - I.block_start;
   const int64_t n_out = off[B];
+  if (a.off_out && blockIdx.x == 0)
+    for (int q = threadIdx.x; q < a.n_slots * (B + 1); q += 256) a.off_out[(int64_t)(q / (B + 1)) * a.off_stride + q % (B + 1)] = tab[q];
   if (I.row_units >= 32) {
     // wide rows (features): one wavefront per row -- the batch position of the row is found ONCE (wave-uniform search in the
     // offset table), then 64 lanes copy the row with coalesced 8-byte (even widths) or 4-byte accesses
@@ -209,12 +213,14 @@ extern "C" void hmp_collator_destroy(hmp_collator* c) {
 }
 
 extern "C" int hmp_collator_run(hmp_collator* c, const int32_t* h_sel, int32_t B, void* const* d_dst, const int64_t* dst_capacity,
-                                int64_t* h_totals, void* stream) {
+                                int64_t* h_totals, int64_t* d_offsets_out, int32_t offsets_stride, void* stream) {
   using namespace hmp;
   HMP_CHECK_ARG(c && h_sel && d_dst && dst_capacity && h_totals && B > 0, "hmp_collator_run: null / empty argument");
   hipStream_t st = (hipStream_t)stream;
   CbArgs a;
   a.n_items = c->n_items; a.B = B; a.n_slots = c->n_slots; a.tables = nullptr;
+  HMP_CHECK_ARG(!d_offsets_out || offsets_stride >= B + 1, "hmp_collator_run: offsets_stride %d < B + 1", offsets_stride);
+  a.off_out = d_offsets_out; a.off_stride = offsets_stride;
   const size_t words = (size_t)c->n_slots * (B + 1) + (size_t)B;
   int64_t* tab = a.inl;
   int slot_i = -1;

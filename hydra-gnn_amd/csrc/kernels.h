@@ -151,6 +151,7 @@ struct AggIn {
 };
 struct AggDst {
   int n_rows, F;
+  int type;  // node type index (graph-local chain: which row-offset vector positions this entry)
   float* out;
   int ldo;
   const float* zroot;  // may be null
@@ -202,6 +203,7 @@ struct TAggOut {
 };
 struct TAggSrc {
   int n_rows;
+  int type;  // node type index
   float* dz;
   int lddz, ncols;     // ncols (padded): columns not covered by a segment are zeroed
   const float* groot;  // may be null
@@ -235,6 +237,24 @@ struct TAggArgs {
 int agg_bwd_launch(TAggArgs& a, hipStream_t st);
 // same + the row-local input-gradient GEMM per 16-row tile (requires every segment width <= 256, ncols <= 896)
 int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st);
+
+// graph-local chain (aggregate.hip: chain_kernel): all launches between the front kernel and the weight-gradient GEMM as phases
+// of ONE launch, one workgroup per graph.  The argument block lives in device memory (several KB).
+constexpr int CHAIN_MAX_LAYERS = 4;
+struct ChainArgs {
+  int L, lds_stride;
+  int gs_last, gs_first;  // row-group widths of the last forward layer / the layer-0 transposed aggregation
+  const int64_t* ptr[HMP_MAX_NODE_TYPES];  // [n_graphs + 1] row offsets of every node type (null: type without rows here)
+  AggArgs fwd[CHAIN_MAX_LAYERS];
+  int fwd_type[CHAIN_MAX_LAYERS][HMP_MAX_NODE_TYPES];  // node type of fwd[l].d[i]
+  TAggArgs bwd[CHAIN_MAX_LAYERS];                       // bwd[l] = layer l
+  int bwd_type[CHAIN_MAX_LAYERS][HMP_MAX_NODE_TYPES];
+  unsigned* ticket;
+  const float* fin_row_lv;
+  float* fin_out2;
+  NetState* fin_state;
+};
+int chain_launch(const ChainArgs* d_args, int n_graphs, int fin_rows, int gs, size_t lds_bytes, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // parameter packing / gradient un-packing (tables live in device memory, built at bind time)

@@ -142,6 +142,22 @@ struct hmp_net {
   hipEvent_t evs[32];
   int n_evs = 0, ev_i = 0;
 
+  // graph-local chain (aggregate.hip: chain_kernel): the aggregation launches of a fused training step are DEFERRED while they
+  // qualify; at the weight-gradient point they run as one launch (or, if anything in between did not qualify, in order as before)
+  struct Deferred {
+    int kind;  // 0 agg_proj_fwd, 1 agg_fwd, 2 agg_bwd_dx, 3 agg_bwd
+    AggArgs fa;
+    TAggArgs ba;
+  };
+  bool chain_try = false;        // this step: defer
+  std::vector<Deferred> deferred;
+  int chain_mode = -1;           // HMP_CHAIN override (0 / 1), -1 = automatic
+  ChainArgs* chain_h = nullptr;  // host copy of what the device holds (pinned)
+  ChainArgs* chain_stage = nullptr;
+  ChainArgs* d_chain = nullptr;
+  hipEvent_t chain_copied = nullptr;
+  bool chain_valid = false;
+
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -630,6 +646,14 @@ struct Scope {
     n->recs.push_back(r);
     idx = (int)n->recs.size() - 1;
   }
+  void cancel() {  // nothing was launched inside (the launch was deferred): drop the record
+    if (idx >= 0 && idx == (int)n->recs.size() - 1) {
+      (void)hipEventDestroy(n->recs[idx].a);
+      (void)hipEventDestroy(n->recs[idx].b);
+      n->recs.pop_back();
+    }
+    idx = -1;
+  }
   ~Scope() {
     if (idx >= 0) (void)hipEventRecord(n->recs[idx].b, st);
   }
@@ -644,7 +668,7 @@ int fork_to(hmp_net* n, hipStream_t from, hipStream_t to) {
   return HMP_OK;
 }
 
-enum { KC_PLAN = 0, KC_PACK, KC_GEMM_FWD, KC_AGG_FWD, KC_LOSS, KC_AGG_BWD, KC_GEMM_BWD, KC_GRAD_REDUCE, KC_ADAM, KC_GAT_FWD, KC_GAT_BWD, KC_POOL, KC_FRONT };
+enum { KC_PLAN = 0, KC_PACK, KC_GEMM_FWD, KC_AGG_FWD, KC_LOSS, KC_AGG_BWD, KC_GEMM_BWD, KC_GRAD_REDUCE, KC_ADAM, KC_GAT_FWD, KC_GAT_BWD, KC_POOL, KC_FRONT, KC_CHAIN };
 
 DropCfg make_drop(const hmp_net* n, float p, uint32_t stream) {
   DropCfg d;
@@ -863,6 +887,115 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
   return true;
 }
 
+// launches what was deferred, in order, as the multi-launch sequence would have
+int chain_flush(hmp_net* n, hipStream_t st) {
+  n->chain_try = false;
+  for (auto& d : n->deferred) {
+    if (d.kind <= 1) {
+      Scope sc(n, KC_AGG_FWD, st);
+      HMP_TRY(d.kind == 0 ? agg_proj_fwd_launch(d.fa, st) : agg_fwd_launch(d.fa, st));
+    } else {
+      Scope sc(n, KC_AGG_BWD, st);
+      HMP_TRY(d.kind == 2 ? agg_bwd_dx_launch(d.ba, st) : agg_bwd_launch(d.ba, st));
+    }
+  }
+  n->deferred.clear();
+  return HMP_OK;
+}
+
+inline int gs_of(int fmax) {  // pick_shape of aggregate.hip for NV == 1 shapes
+  int gs = 8;
+  const int lanes = (fmax + 3) / 4;
+  while (gs < 64 && gs < lanes) gs <<= 1;
+  return gs;
+}
+inline int gs_tile(int fmax) {  // agg_proj_fwd_launch / agg_bwd_dx_launch
+  int gs = 16;
+  while (gs < 64 && gs * 4 < fmax) gs <<= 1;
+  return gs;
+}
+
+// everything deferred -> ONE chain launch, if the recorded sequence is exactly {L-1 x agg+proj, agg+CE, L-1 x aggT+dX, aggT} of one
+// tile shape; else the multi-launch sequence
+int chain_run(hmp_net* n, hipStream_t st) {
+  if (!n->chain_try) return HMP_OK;
+  const hmp_batch* b = &n->batch;
+  const int L = n->L;
+  bool ok = (int)n->deferred.size() == 2 * L && L >= 1 && L <= CHAIN_MAX_LAYERS && b->n_graphs > 0;
+  int gs = 0, gs_last = 0, gs_first = 0, kmax = 0;
+  for (int i = 0; ok && i < 2 * L; ++i) {
+    const hmp_net::Deferred& d = n->deferred[i];
+    const int want = i < L - 1 ? 0 : (i == L - 1 ? 1 : (i < 2 * L - 1 ? 2 : 3));
+    if (d.kind != want) { ok = false; break; }
+    int fmax = 0;
+    if (d.kind <= 1) {
+      for (int q = 0; q < d.fa.n; ++q) fmax = d.fa.d[q].F > fmax ? d.fa.d[q].F : fmax;
+      if (d.kind == 0) { const int g = gs_tile(fmax); if (gs && g != gs) ok = false; gs = g; }
+      else {
+        gs_last = gs_of(fmax);
+        for (int q = 0; q < d.fa.n; ++q) if (!d.fa.d[q].ce_labels) ok = false;  // the readout rows carry the loss
+        if (d.fa.zb16 || d.fa.hb16) ok = false;
+      }
+    } else {
+      for (int q = 0; q < d.ba.n; ++q) {
+        for (int o = 0; o < d.ba.s[q].n_out; ++o) fmax = d.ba.s[q].out[o].F > fmax ? d.ba.s[q].out[o].F : fmax;
+        if (d.ba.s[q].groot) fmax = d.ba.s[q].Froot > fmax ? d.ba.s[q].Froot : fmax;
+        kmax = d.ba.s[q].ncols > kmax ? d.ba.s[q].ncols : kmax;
+      }
+      if (d.kind == 2) { const int g = gs_tile(fmax); if (gs && g != gs) ok = false; gs = g; }
+      else { gs_first = gs_of(fmax); if (d.ba.gb16 || d.ba.dzb16) ok = false; }
+    }
+  }
+  if (L == 1) gs = 16;
+  const int stride = (256 * 17 > kmax * 17) ? 256 * 17 : kmax * 17;
+  const size_t lds = (size_t)2 * stride * sizeof(float);  // CHAIN_GROUPS = 2 groups of 256 threads
+  if (ok) ok = (gs == 16 || gs == 32) && gs_last <= 32 && gs_first <= 32 && lds + sizeof(ChainArgs) + 16 <= 150 * 1024;
+  if (!ok) return chain_flush(n, st);
+  // ---- argument block
+  if (!n->chain_h) {
+    HMP_HIP(hipHostMalloc((void**)&n->chain_h, sizeof(ChainArgs), hipHostMallocDefault));
+    HMP_HIP(hipHostMalloc((void**)&n->chain_stage, sizeof(ChainArgs), hipHostMallocDefault));
+    HMP_HIP(hipMalloc((void**)&n->d_chain, sizeof(ChainArgs)));
+    HMP_HIP(hipEventCreateWithFlags(&n->chain_copied, hipEventDisableTiming));
+    n->chain_valid = false;
+  }
+  ChainArgs& C = *n->chain_stage;
+  HMP_HIP(hipEventSynchronize(n->chain_copied));  // the previous upload has left the staging buffer (no-op when none is pending)
+  memset(&C, 0, sizeof(C));
+  C.L = L; C.lds_stride = stride; C.gs_last = gs_last; C.gs_first = gs_first;
+  for (int t = 0; t < n->T; ++t) C.ptr[t] = b->d_node_ptr[t];
+  for (int l = 0; l < L; ++l) {
+    C.fwd[l] = n->deferred[l].fa;
+    for (int q = 0; q < C.fwd[l].n; ++q) { C.fwd_type[l][q] = C.fwd[l].d[q].type; C.fwd[l].d[q].n_rows = 0; C.fwd[l].d[q].block_start = 0; }
+    C.fwd[l].total_blocks = 0;
+    TAggArgs& B = C.bwd[L - 1 - (l)];  // deferred[L + j] is layer L - 1 - j
+    B = n->deferred[L + l].ba;
+    for (int q = 0; q < B.n; ++q) { C.bwd_type[L - 1 - l][q] = B.s[q].type; B.s[q].n_rows = 0; B.s[q].block_start = 0; }
+    B.total_blocks = 0;
+    if (B.fin_row_lv) { C.fin_row_lv = B.fin_row_lv; C.fin_out2 = B.fin_out2; C.fin_state = B.fin_state; }
+    B.fin_row_lv = nullptr; B.fin_rows = 0; B.fin_out2 = nullptr; B.fin_state = nullptr;
+  }
+  C.ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(n->d_state) + 128);
+  for (int t = 0; t < n->T; ++t) {  // every node type an entry works on needs its row offsets
+    bool used = false;
+    for (int l = 0; l < L; ++l) {
+      for (int q = 0; q < C.fwd[l].n; ++q) used = used || C.fwd_type[l][q] == t;
+      for (int q = 0; q < C.bwd[l].n; ++q) used = used || C.bwd_type[l][q] == t;
+    }
+    if (used && !C.ptr[t]) return chain_flush(n, st);
+  }
+  if (!n->chain_valid || memcmp(&C, n->chain_h, sizeof(ChainArgs)) != 0) {
+    memcpy(n->chain_h, &C, sizeof(ChainArgs));
+    HMP_HIP(hipMemcpyAsync(n->d_chain, n->chain_stage, sizeof(ChainArgs), hipMemcpyHostToDevice, st));
+    HMP_HIP(hipEventRecord(n->chain_copied, st));
+    n->chain_valid = true;
+  }
+  n->deferred.clear();
+  n->chain_try = false;
+  Scope sc(n, KC_CHAIN, st);
+  return chain_launch(n->d_chain, b->n_graphs, b->n_out, gs, lds, st);
+}
+
 int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStream_t st) {
   HMP_TRY(check_batch(n, b));
   n->batch = *b;
@@ -908,6 +1041,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     if (l == 0 && front) {
       // projection, plan and pack already ran in the front kernel
     } else if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
+      HMP_TRY(chain_flush(n, st));
       Scope sc(n, KC_GEMM_FWD, st);
       std::vector<GemmProblem> ps;
       for (int s = 0; s < n->T; ++s) {
@@ -950,6 +1084,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
       st = main_st;
     }
     if (Y.kind == HMP_CONV_GAT) {
+      HMP_TRY(chain_flush(n, st));
       Scope sc(n, KC_GAT_FWD, st);
       GatDyn dyn = make_gat_dyn(n, b);
       HMP_TRY(gat_fwd_launch(Y.d_gat, Y.h_gat, dyn, st));
@@ -971,6 +1106,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           n->ce_done = true;
         }
         D.n_rows = b->n_nodes[t];
+        D.type = t;
         D.F = fpad(Ls.out_dim[t]);
         D.out = n->H[l + 1][t]; D.ldo = n->ld[l + 1][t];
         D.zroot = n->Z[l][t]; D.ldzr = Y.ncols[t]; D.roff = Y.roff[t];
@@ -1013,7 +1149,14 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           D.pw = n->d_packed + Yn.wp_off[t]; D.pldw = Yn.ldw[t]; D.pncols = Yn.ncols[t]; D.pK = n->dim[l + 1][t];
           D.pz = n->Z[l + 1][t]; D.pldz = Yn.ncols[t];
         }
-        HMP_TRY(agg_proj_fwd_launch(a, st));
+        if (n->chain_try) {
+          hmp_net::Deferred d;
+          d.kind = 0; d.fa = a;
+          n->deferred.push_back(d);
+          sc.cancel();
+        } else {
+          HMP_TRY(agg_proj_fwd_launch(a, st));
+        }
         z_done = true;
       } else {
         a.zb16 = z16 ? 1 : 0;
@@ -1037,11 +1180,20 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           for (int t = 0; t < n->T; ++t)
             if (Y.roff[t] >= 0 && b->n_nodes[t] > 0) n->h16[l + 1][t] = true;
         }
-        HMP_TRY(agg_fwd_launch(a, st));
+        if (n->chain_try && n->fuse_now && !z16) {
+          hmp_net::Deferred d;
+          d.kind = 1; d.fa = a;
+          n->deferred.push_back(d);
+          sc.cancel();
+        } else {
+          HMP_TRY(chain_flush(n, st));
+          HMP_TRY(agg_fwd_launch(a, st));
+        }
       }
     }
   }
   if (S.pool_edge_type >= 0) {
+    HMP_TRY(chain_flush(n, st));
     Scope sc(n, KC_POOL, st);
     const int rt = S.readout_type;
     HMP_TRY(hmp_segment_mean_fwd(n->H[n->L][rt], n->ld[n->L][rt], n->out_ld, n->plan[S.pool_edge_type], n->d_out, n->out_ld, st));
@@ -1079,6 +1231,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
   const float* gtop = d_gout;
   int ld_gtop = ld_gout;
   if (S.pool_edge_type >= 0) {
+    HMP_TRY(chain_flush(n, st));
     Scope sc(n, KC_POOL, st);
     HMP_TRY(hmp_segment_mean_bwd(d_gout, ld_gout, n->out_ld, n->plan[S.pool_edge_type], n->G[n->L][rt], n->ld[n->L][rt], st));
     gtop = n->G[n->L][rt];
@@ -1111,6 +1264,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     bool rootless = false;  // this layer's GEMMs take the root block of dZ from the output gradient
     dz16 = false;
     if (Y.kind == HMP_CONV_GAT) {
+      HMP_TRY(chain_flush(n, st));
       Scope sc(n, KC_GAT_BWD, st);
       GatDyn dyn = make_gat_dyn(n, b);
       dyn.g_top = gtop; dyn.ld_gtop = ld_gtop;
@@ -1130,6 +1284,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
         TAggSrc& T = a.s[a.n++];
         T.n_rows = b->n_nodes[s];
+        T.type = s;
         T.dz = n->dZ[l][s]; T.lddz = Y.ncols[s]; T.ncols = Y.ncols[s];
         if (Y.roff[s] >= 0) {
           int ldg;
@@ -1174,7 +1329,14 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           T.xh = (T.xact != HMP_ACT_NONE || T.xdrop_on) ? n->H[l][s] : nullptr;
           T.xldh = n->ld[l][s];
         }
-        HMP_TRY(agg_bwd_dx_launch(a, st));
+        if (n->chain_try) {
+          hmp_net::Deferred d;
+          d.kind = 2; d.ba = a;
+          n->deferred.push_back(d);
+          sc.cancel();
+        } else {
+          HMP_TRY(agg_bwd_dx_launch(a, st));
+        }
       } else {
         a.gb16 = g16[l + 1] ? 1 : 0;
         // dZ as bf16 too (it is only read back as the A operand of the two backward GEMMs): needs the bf16-reading kernel
@@ -1199,7 +1361,15 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         }
         if (rootless)
           for (int i = 0; i < a.n; ++i) a.s[i].groot = nullptr;
-        HMP_TRY(agg_bwd_launch(a, st));
+        if (n->chain_try && n->fuse_now && l == 0 && !a.gb16) {
+          hmp_net::Deferred d;
+          d.kind = 3; d.ba = a;
+          n->deferred.push_back(d);
+          sc.cancel();
+        } else {
+          HMP_TRY(chain_flush(n, st));
+          HMP_TRY(agg_bwd_launch(a, st));
+        }
       }
     }
     // dZ[l] is complete.  Weight-gradient GEMMs: either ALL layers in one grouped split-K launch after the loop
@@ -1212,6 +1382,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     }
     const bool need_dx = !dx_fused && ((l > 0) || (d_gx != nullptr));
     if (need_dx) {  // input gradient, masked by the previous layer's activation/dropout derivative
+      HMP_TRY(chain_flush(n, st));
       Scope sc(n, KC_GEMM_BWD, st);
       std::vector<GemmProblem> ps;
       for (int s = 0; s < n->T; ++s) {
@@ -1316,6 +1487,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         }
       }
       if (n->dw_branch) {
+        HMP_TRY(chain_flush(n, st));
         Scope sc(n, KC_GEMM_BWD, wst);
         std::vector<int> ks;
         HMP_TRY(gemm_many(ps, true, wst, &ks, n->compute_bf16 != 0));
@@ -1323,6 +1495,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       }
     }
   }
+  HMP_TRY(chain_run(n, st));  // the deferred aggregation launches: as one graph-local launch, or in order
   if (n->dw_branch) {
     if (n->use_branches) HMP_TRY(fork_to(n, n->side[1], st));  // join the weight-gradient branch
   } else {
@@ -1407,6 +1580,8 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
     n->dw_mode = db ? (db[0] == '1' ? 1 : 0) : -1;  // -1: decide per batch (see backward_impl)
     const char* fz = getenv("HMP_FUSE");
     n->fuse_mode = fz ? (fz[0] == '1' ? 1 : 0) : -1;
+    const char* cz = getenv("HMP_CHAIN");
+    n->chain_mode = cz ? (cz[0] == '1' ? 1 : 0) : -1;
   }
   if (r != HMP_OK) {
     hmp_net_destroy(n);
@@ -1423,6 +1598,10 @@ extern "C" void hmp_net_destroy(hmp_net* n) {
   for (int i = 0; i < 2; ++i)
     if (n->side[i]) (void)hipStreamDestroy(n->side[i]);
   if (n->d_state) (void)hipFree(n->d_state);
+  if (n->chain_h) (void)hipHostFree(n->chain_h);
+  if (n->chain_stage) (void)hipHostFree(n->chain_stage);
+  if (n->d_chain) (void)hipFree(n->d_chain);
+  if (n->chain_copied) (void)hipEventDestroy(n->chain_copied);
   if (n->d_pack_segs) (void)hipFree(n->d_pack_segs);
   if (n->d_pack_map) (void)hipFree(n->d_pack_map);
   if (n->d_grad_segs) (void)hipFree(n->d_grad_segs);
@@ -1460,6 +1639,8 @@ extern "C" int hmp_net_forward(hmp_net* n, const hmp_batch* batch, const float* 
                                uint32_t rng_step, const float** d_out, int32_t* ld_out, void* stream) {
   HMP_CHECK_ARG(n && batch && d_params && d_out && ld_out, "hmp_net_forward: null argument");
   n->training = training; n->seed = seed; n->rng_step = rng_step; n->step_dev = false;
+  n->chain_try = false;
+  n->deferred.clear();
   HMP_TRY(forward_impl(n, batch, d_params, (hipStream_t)stream));
   *d_out = out_ptr(n);
   *ld_out = n->out_ld;
@@ -1519,17 +1700,28 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
   n->training = args->training; n->seed = args->seed; n->rng_step = 0; n->step_dev = true;
   n->d_step = args->d_step ? args->d_step : &n->d_state->step;
   n->ce_labels = batch->d_labels; n->ce_ignored = args->ignored_label; n->ce_done = false;
+  // graph-local chain: a batch that says where its graphs begin (Batch.ptr), SAGE stacks, no pooled readout.
+  n->deferred.clear();
+  // MEASURED SLOWER than the multi-launch sequence (profiles/r02_c_graph_local_chain.md: 0.239 ms against 0.048 ms for the five launches
+  // it replaces on config 2): a graph's 7 tiles take 4 rounds of 2 per phase and a round is one full dependent-load chain, whereas the
+  // multi-launch sequence runs every tile of every graph at once.  Opt-in only (HMP_CHAIN=1), kept for its test and as the record.
+  n->chain_try = n->chain_mode == 1 && !n->any_gat && n->spec.pool_edge_type < 0 && n->L <= CHAIN_MAX_LAYERS && batch->n_graphs > 0 &&
+                 batch->max_graph_nodes > 0 && batch->max_graph_nodes <= 4096 && !n->use_branches;
   const int rf = forward_impl(n, batch, d_params, st);
   n->ce_labels = nullptr;
+  if (rf != HMP_OK) { n->chain_try = false; n->deferred.clear(); }
   HMP_TRY(rf);
   if (!n->ce_done) {
+    HMP_TRY(chain_flush(n, st));
     Scope sc(n, KC_LOSS, st);
     HMP_TRY(masked_ce_rows_launch(out_ptr(n), n->out_ld, batch->n_out, n->out_dim, batch->d_labels, args->ignored_label, n->d_gout,
                                   n->out_ld, n->d_row_lv, n->d_state, st));
   }
   // {loss_sum, count} -> d_grads[na], d_grads[na + 1]: by the first transposed aggregation, else by the gradient un-pack
   n->fin_loss = true;
-  return backward_impl(n, n->d_gout, n->out_ld, d_grads, d_params, nullptr, st);
+  const int rb = backward_impl(n, n->d_gout, n->out_ld, d_grads, d_params, nullptr, st);
+  if (rb != HMP_OK) { n->chain_try = false; n->deferred.clear(); }
+  return rb;
 }
 
 extern "C" int hmp_net_step_fused(hmp_net* n, const hmp_batch* batch, float* d_params, float* d_grads, float* d_m, float* d_v,

@@ -14,9 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMP_LIB") or os.path.join(HERE, "libhydra_mp.so")
 
 MAX_NODE_TYPES, MAX_EDGE_TYPES, MAX_LAYERS, MAX_CONVS = 8, 16, 8, 16
-N_KCLASS = 13
+N_KCLASS = 14
 KCLASS_NAMES = ["plan", "pack", "gemm_fwd", "aggregate_fwd", "loss", "aggregate_bwd", "gemm_bwd", "grad_reduce",
-                "adam", "gat_fwd", "gat_bwd", "pool", "front"]
+                "adam", "gat_fwd", "gat_bwd", "pool", "front", "chain"]
 CONV_SAGE, CONV_GAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 
@@ -79,6 +79,9 @@ class Batch(C.Structure):
         ("n_out", C.c_int32),
         ("d_labels", C.c_void_p),
         ("plan_valid", C.c_int32),
+        ("d_node_ptr", C.c_void_p * MAX_NODE_TYPES),
+        ("n_graphs", C.c_int32),
+        ("max_graph_nodes", C.c_int32),
     ]
 
 
@@ -156,7 +159,7 @@ SIGNATURES = {
     "hmp_batchnorm_fwd": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _F32, _F32, _I32, _VP, _I32, _VP, _VP]),
     "hmp_batchnorm_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP, _I32, _VP, _VP, _VP]),
     "hmp_collator_create": (C.c_int, [_I32, C.POINTER(_VP), _I64, _I32, C.POINTER(CollateItem), C.POINTER(_VP)]),
-    "hmp_collator_run": (C.c_int, [_VP, _VP, _I32, C.POINTER(_VP), C.POINTER(_I64), C.POINTER(_I64), _VP]),
+    "hmp_collator_run": (C.c_int, [_VP, _VP, _I32, C.POINTER(_VP), C.POINTER(_I64), C.POINTER(_I64), _VP, _I32, _VP]),
     "hmp_collator_destroy": (None, [_VP]),
     "hmp_htree_build": (C.c_int, [_I32, _I32, _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
     "hmp_htree_sizes": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)]),

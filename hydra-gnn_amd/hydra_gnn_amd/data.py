@@ -161,7 +161,7 @@ class HeteroData:
         out = type(self)()
         out._nodes = {k: s._map(lambda t: t.to(device)) for k, s in self._nodes.items()}
         out._edges = {k: s._map(lambda t: t.to(device)) for k, s in self._edges.items()}
-        for name in ("num_graphs",):
+        for name in ("num_graphs", "max_graph_nodes"):
             if hasattr(self, name):
                 setattr(out, name, getattr(self, name))
         return out
@@ -232,6 +232,7 @@ def collate(graphs: Sequence[HeteroData]) -> HeteroData:
     out.num_graphs = len(graphs)
     node_types = graphs[0].node_types
     offsets: Dict[str, List[int]] = {}
+    max_nodes = 0
     for nt in node_types:
         counts = [g[nt].num_nodes for g in graphs]
         off = [0]
@@ -247,6 +248,7 @@ def collate(graphs: Sequence[HeteroData]) -> HeteroData:
             torch.arange(len(graphs), dtype=torch.int64), torch.tensor(counts, dtype=torch.int64)
         )
         out[nt].ptr = torch.tensor(off, dtype=torch.int64)
+        max_nodes = max(max_nodes, max(counts))
     for et in graphs[0].edge_types:
         src, _, dst = et
         parts = []
@@ -257,6 +259,8 @@ def collate(graphs: Sequence[HeteroData]) -> HeteroData:
         out[et].edge_index = torch.cat(parts, dim=1)
         if "edge_attr" in graphs[0][et]:
             out[et].edge_attr = torch.cat([g[et].edge_attr for g in graphs], dim=0)
+    # host knowledge of the collation: lets the engine run the per-graph phases of a training step as one launch (hmp_batch)
+    out.max_graph_nodes = int(max_nodes)
     return out
 
 

@@ -310,6 +310,26 @@ class NativeNet:
         nt = {t: i for i, t in enumerate(self.node_types)}
         out_type = self.pool_edge_type[2] if self.pool_edge_type is not None else self.readout
         h.c.n_out = h.n_nodes[nt[out_type]]
+        # the batch as a union of graphs ([PyG] Batch.ptr per node store + the collation's host-side maximum): optional
+        mg = int(getattr(data, "max_graph_nodes", 0) or 0)
+        ng = 0
+        if mg > 0:
+            for i, t in enumerate(self.node_types):
+                st_ = data[t] if t in x_dict else None
+                p = getattr(st_, "ptr", None) if st_ is not None else None
+                if p is None or not p.is_cuda or p.dtype != torch.int64 or not p.is_contiguous() or int(p[-1:].numel()) == 0:
+                    if h.n_nodes[i] > 0:
+                        ng = 0
+                        break
+                    continue
+                if ng and p.numel() - 1 != ng:
+                    ng = 0
+                    break
+                ng = p.numel() - 1
+                h.keep.append(p)
+                h.c.d_node_ptr[i] = p.data_ptr()
+        h.c.n_graphs = ng
+        h.c.max_graph_nodes = mg if ng else 0
         if labels is not None:
             _require_cuda(labels, "labels")
             lab = labels.to(torch.int64).contiguous()

@@ -205,6 +205,9 @@ class BatchStream:
         self._dst = (C.c_void_p * n_items)(*[b.data_ptr() for b in self._bufs])
         self._caps = (C.c_int64 * n_items)(*[self.cap[it.slot] for it in items])
         self._totals = (C.c_int64 * len(slots))()
+        # Batch.ptr of every slot, written by the collation kernel (the executor's graph-local launch reads the node types' rows)
+        self._off_stride = self.B + 1
+        self._offsets = torch.zeros(len(slots) * self._off_stride, dtype=torch.int64, device=dev)
         self._slots, self._slot_of = slots, slot_of
         # ---- the executor's descriptor, filled once; per batch only the counts change
         from .engine import _BatchHolder
@@ -235,7 +238,10 @@ class BatchStream:
         if lab.dtype != torch.int64:
             raise _lib.HydraMPError("labels in the store must be int64")
         hd.c.d_labels = lab.data_ptr()
-        hd.keep = list(self._bufs)
+        hd.keep = list(self._bufs) + [self._offsets]
+        for i, t in enumerate(nat.node_types):
+            hd.c.d_node_ptr[i] = self._offsets.data_ptr() + 8 * slot_of[t] * self._off_stride
+        hd.c.max_graph_nodes = int(max(int(np.diff(host_ptrs[slot_of[t]]).max()) for t in store.node_types))
         hd.n_nodes = [0] * len(nat.node_types)
         hd.n_edges = [0] * len(nat.edge_types)
         out_type = nat.pool_edge_type[2] if nat.pool_edge_type is not None else nat.readout
@@ -258,7 +264,8 @@ class BatchStream:
         B = int(sel.size)
         if B > self.B:
             raise _lib.HydraMPError(f"{B} graphs for a stream of batch size {self.B}")
-        _lib.check(self.store.lib.hmp_collator_run(self._h, sel.ctypes.data, B, self._dst, self._caps, self._totals, _lib.stream_ptr()))
+        _lib.check(self.store.lib.hmp_collator_run(self._h, sel.ctypes.data, B, self._dst, self._caps, self._totals,
+                                                   self._offsets.data_ptr(), self._off_stride, _lib.stream_ptr()))
         hd, tot = self.holder, self._totals
         for i, s in enumerate(self._node_slot):
             v = tot[s]
@@ -269,6 +276,7 @@ class BatchStream:
             hd.c.n_edges[i] = v
             hd.n_edges[i] = v
         hd.c.n_out = tot[self._out_slot]
+        hd.c.n_graphs = B
         self.num_graphs = B
         return hd
 

@@ -224,6 +224,12 @@ typedef struct hmp_batch {
   int32_t plan_valid;        /* != 0: the caller vouches that every edge list equals the previous call's (same topology, e.g.
                               * consecutive frames of the inference server, bin/room_classification_server:273-299): the CSR /
                               * CSC plan in the workspace is reused instead of rebuilt.  Counts must match the previous call. */
+  /* optional: the batch as a disjoint union of graphs ([PyG] Batch.ptr per node type; base_training_job.py:164-168 collates
+   * that way).  With it the small-batch training step runs everything between the first aggregation and the weight gradients
+   * as ONE launch, one workgroup per graph.  n_graphs = 0: unknown (any edge structure is accepted, multi-launch sequence). */
+  const int64_t* d_node_ptr[HMP_MAX_NODE_TYPES]; /* [n_graphs + 1] int64 row offsets of the node type, or NULL */
+  int32_t n_graphs;
+  int32_t max_graph_nodes;   /* largest per-graph node count over all types (host knowledge of the collation), 0 = unknown */
 } hmp_batch;
 
 typedef struct hmp_train_args {
@@ -304,8 +310,9 @@ void hmp_timer_destroy(hmp_timer* t);
 /* per-kernel-class device time accumulated by the executor when profiling is on (HIP events around
  * every launch of that class on the executor's stream).  classes: 0 plan, 1 pack, 2 gemm_fwd,
  * 3 aggregate_fwd, 4 loss, 5 aggregate_bwd, 6 gemm_bwd, 7 grad_reduce, 8 adam, 9 gat_fwd, 10 gat_bwd, 11 pool,
- * 12 front (layer-0 projection + plan + pack in one launch, small batches) */
-#define HMP_N_KCLASS 13
+ * 12 front (layer-0 projection + plan + pack in one launch, small batches), 13 chain (graph-local launch: every aggregation
+ * phase of the step, one workgroup per graph) */
+#define HMP_N_KCLASS 14
 int hmp_net_profile(hmp_net* net, int32_t enable);
 int hmp_net_profile_read(hmp_net* net, float* ms_sum /*[HMP_N_KCLASS]*/, int32_t* launches /*[HMP_N_KCLASS]*/);
 
@@ -327,7 +334,8 @@ int hmp_collate_edges(const int64_t* d_src, int64_t e_total, const int64_t* d_ed
  *   items   the output arrays: rows (row_bytes > 0: x / y / pos / edge_attr, positioned by `slot`) or an edge_index
  *           (row_bytes == 0: int64 [2][src_total], positioned by `slot`, endpoints shifted by `slot_src` / `slot_dst`).
  * hmp_collator_run: h_sel [B] graph ids (host), d_dst[i] / dst_capacity[i] per item (rows resp. edges), h_totals[slot] receives
- * the batch's node / edge totals (the shapes of the outputs).  No allocation or synchronisation in the steady state. */
+ * the batch's node / edge totals (the shapes of the outputs).  No allocation or synchronisation in the steady state.
+ * (<= 356 words of offsets + selection travel in the kernel's argument block, larger batches through a pinned ring.) */
 typedef struct hmp_collate_item {
   const void* d_src;
   const int64_t* d_ptr;      /* device copy of the item's [G + 1] offsets */
@@ -339,7 +347,8 @@ typedef struct hmp_collator hmp_collator; /* opaque */
 int hmp_collator_create(int32_t n_slots, const int64_t* const* h_slot_ptr, int64_t n_graphs, int32_t n_items,
                         const hmp_collate_item* items, hmp_collator** out);
 int hmp_collator_run(hmp_collator* c, const int32_t* h_sel, int32_t B, void* const* d_dst, const int64_t* dst_capacity,
-                     int64_t* h_totals, void* stream);
+                     int64_t* h_totals, int64_t* d_offsets_out /* NULL or [n_slots][offsets_stride]: Batch.ptr of every slot */,
+                     int32_t offsets_stride, void* stream);
 void hmp_collator_destroy(hmp_collator* c);
 
 /* ---------------------------------------------------------------------------------------------

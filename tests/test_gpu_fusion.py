@@ -457,3 +457,75 @@ def test_standalone_sequence_at_the_reference_batch_scale_matches_the_oracle(mon
             # sums over 46 000 nodes in fp32: 1e-5 relative + 1e-5 of the tensor's scale
             scale = max(float(p.grad.abs().max()), 1.0)
             torch.testing.assert_close(grads[name].cpu().double(), p.grad, atol=ATOL * scale, rtol=RTOL, msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("n_graphs,hidden,layers", [(1, 64, 3), (7, 64, 3), (32, 64, 3), (5, 32, 2), (6, 64, 4)])
+def test_graph_local_chain_launch_is_bit_identical(n_graphs, hidden, layers, monkeypatch):
+    """OPT-IN (HMP_CHAIN=1; measured slower than the multi-launch sequence, profiles/r02_c_graph_local_chain.md).
+    A collated batch tells the engine where its graphs begin (Batch.ptr + max_graph_nodes): the fused training step then runs
+    every aggregation phase -- L-1 x (aggregation + next projection), aggregation + masked CE, L-1 x (transposed aggregation +
+    input gradient), transposed aggregation, loss finalisation -- as ONE launch with one workgroup per graph (chain_kernel).
+    The phases are the tile / row routines of the multi-launch kernels: losses and parameters must be bit-identical to
+    HMP_CHAIN=0 step after step, in training mode with dropout and Adam."""
+    kw = dict(SAGE_KW, hidden_dim=hidden, num_layers=layers, dropout=0.25)
+    batch = workloads.mp3d_like_batch(n_graphs, seed=40 + n_graphs)
+    assert batch.max_graph_nodes > 0 and batch["rooms"].ptr.numel() == n_graphs + 1
+
+    def run(chain):
+        monkeypatch.setenv("HMP_CHAIN", chain)
+        torch.manual_seed(5)
+        net = HeterogeneousNetwork(**kw).to(DEV)
+        net.train()
+        gb = batch.to(DEV)
+        step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=9, use_graph=False)
+        losses = []
+        for _ in range(4):
+            step(gb, gb["rooms"].y)
+            losses.append(step.loss())
+        nat = net.native()
+        lib = nat._lib
+        # which launch classes ran in one more, profiled step
+        import ctypes as C
+        from hydra_gnn_amd import _lib
+        _lib.check(lib.hmp_net_profile(nat._handle, 1))
+        step(gb, gb["rooms"].y)
+        torch.cuda.synchronize()
+        ms = (C.c_float * _lib.N_KCLASS)()
+        ln = (C.c_int32 * _lib.N_KCLASS)()
+        _lib.check(lib.hmp_net_profile_read(nat._handle, ms, ln))
+        _lib.check(lib.hmp_net_profile(nat._handle, 0))
+        launches = dict(zip(_lib.KCLASS_NAMES, list(ln)))
+        assert nat.read_state()[1] == 0
+        return losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone(), launches
+
+    l0, p0, k0 = run("0")
+    l1, p1, k1 = run("1")
+    assert k0["chain"] == 0 and k0["aggregate_fwd"] == layers and k0["aggregate_bwd"] == layers
+    assert k1["chain"] == 1 and k1["aggregate_fwd"] == 0 and k1["aggregate_bwd"] == 0, k1
+    assert l0 == l1
+    assert torch.equal(p0, p1)
+
+
+def test_graph_local_chain_is_skipped_without_graph_boundaries(monkeypatch):
+    """A batch that does not say where its graphs begin (no ptr / max_graph_nodes) takes the multi-launch sequence; so does the
+    autograd path (forward / backward as separate calls)."""
+    monkeypatch.setenv("HMP_CHAIN", "1")
+    batch = workloads.mp3d_like_batch(4, seed=3)
+    del batch.max_graph_nodes
+    torch.manual_seed(0)
+    net = HeterogeneousNetwork(**dict(SAGE_KW, dropout=0.25)).to(DEV)
+    net.train()
+    gb = batch.to(DEV)
+    step = net.train_step(lr=0.002, ignored_label=25, use_graph=False)
+    import ctypes as C
+    from hydra_gnn_amd import _lib
+    nat = net.native()
+    step(gb, gb["rooms"].y)
+    _lib.check(nat._lib.hmp_net_profile(nat._handle, 1))
+    step(gb, gb["rooms"].y)
+    torch.cuda.synchronize()
+    ms = (C.c_float * _lib.N_KCLASS)(); ln = (C.c_int32 * _lib.N_KCLASS)()
+    _lib.check(nat._lib.hmp_net_profile_read(nat._handle, ms, ln))
+    _lib.check(nat._lib.hmp_net_profile(nat._handle, 0))
+    launches = dict(zip(_lib.KCLASS_NAMES, list(ln)))
+    assert launches["chain"] == 0 and launches["aggregate_fwd"] == 3
