@@ -17,6 +17,8 @@
 //
 // Forms: NT (x * W^T, nn.Linear), NN (dZ * W, input gradient, optional activation-derivative epilogue),
 // TN with split-K over node chunks (dZ^T * [x | 1], weight + bias gradient; slabs are reduced later).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace hmp {
@@ -210,11 +212,15 @@ __device__ __forceinline__ int vec_mode(const float* p, int ld, bool k_ok) {
 
 // FORM fixes the operand layouts at compile time (0: NT = x * W^T, 1: NN = dZ * W, 2: TN = dZ^T * [x | 1]; 3: per problem at run
 // time): with run-time layouts the layout branch sits inside the unrolled load loops and the loads stop overlapping.
-template <int WM, int WN, int BK, int FORM>
+// MI x NI 32x32 accumulator tiles per wave (round 2): <2,2,32,.,2,2> = a 128x128 tile, every operand fragment fetched from LDS
+// feeds two MFMAs instead of one and the tile re-reads A / B from L2 half as often -- the 64x64 form ran the big problems
+// (GAT projections, batch-2048 weight gradients) at 34-60 TFLOP/s, bound by L2 -> CU operand traffic at 16 flop per byte.
+template <int WM, int WN, int BK, int FORM, int MI = 1, int NI = 1>
 // second launch-bound = waves per SIMD = blocks per CU for 256-thread blocks: >= 3 so that the ~600 workgroups of an MP3D
 // layer-0 projection are all resident at once (one round instead of two)
-__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
-  constexpr int BM = 32 * WM, BN = 32 * WN, KW = 4 / (WM * WN);
+__global__ __launch_bounds__(256, (MI * NI > 1) ? 2 : 3) void gemm_kernel(const GemmBatch gb) {
+  constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI, KW = 4 / (WM * WN);
+  static_assert(MI * NI == 1 || KW == 1, "register tiling only with one K group");
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int STAGE = BK * LDA + BK * LDB;
   constexpr int RED = (KW > 1) ? (KW - 1) * 16 * 64 : 0;
@@ -253,9 +259,14 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w % WM, wn = (w / WM) % WN, kw = w / (WM * WN);
 
-  f32x16 acc;
+  f32x16 acc_t[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_t[i][j][r] = 0.f;
+  f32x16& acc = acc_t[0][0];
 
   TileRegs<BM, BK> ra;
   TileRegs<BN, BK> rb;
@@ -279,14 +290,20 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
     }
     constexpr int KS = BK / KW;
     const int klen = min(BK, kend - kt);  // tail stage: skip the k rows that are all zero
-    const int ma = wm * 32 + (lane & 31), mb = wn * 32 + (lane & 31);
+    const int ma = wm * 32 * MI + (lane & 31), mb = wn * 32 * NI + (lane & 31);
     // KS is a multiple of 4 and kk is even, so (k >> 2) does not depend on the lane half: the rotation is uniform
     auto mfma_pair = [&](int kk) {
       const int k = kw * KS + kk + (lane >> 5);
       const int rot = (kw * KS + kk) >> 2;
-      const int ca = a_kcontig ? ((ma + rot) & (BM - 1)) : ma;  // undo the store rotation
-      const int cb = b_kcontig ? ((mb + rot) & (BN - 1)) : mb;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * LDA + ca], Bs[k * LDB + cb], acc, 0, 0, 0);
+      float av[MI], bv[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) av[i] = As[k * LDA + (a_kcontig ? ((ma + 32 * i + rot) & (BM - 1)) : ma + 32 * i)];  // undo the store rotation
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bv[j] = Bs[k * LDB + (b_kcontig ? ((mb + 32 * j + rot) & (BN - 1)) : mb + 32 * j)];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc_t[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc_t[i][j], 0, 0, 0);
     };
     if (klen == BK) {
       // full stage: straight-line code, so the scheduler can run the LDS operand reads ahead of the MFMAs
@@ -327,39 +344,45 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmBatch gb) {
   // No branch between memory operations: fields in registers, the 16 activation values requested together (clamped addresses),
   // predicated stores.  (With a `continue` per element the compiler waited for every H load before issuing the next one.)
   float* C = P.C + (int64_t)z * P.slab_stride;
-  const int col = n0 + wn * 32 + (lane & 31);
-  if (col >= P.N) return;
-  const int Mrows = P.M, ldc = P.ldc, ldh = P.ldh, act = P.act;
+  const int Mrows = P.M, Ncols = P.N, ldc = P.ldc, ldh = P.ldh, act = P.act;
   const bool amask = P.epi == EPI_ACTMASK;
   const bool dropon = P.drop_on != 0;
   const float dscale = dropon ? P.drop.scale : 1.f;
   const float* Hp = P.H;
-  const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
-  float hv[16];
-  if (amask) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rbase + (r & 3) + 8 * (r >> 2);
-      hv[r] = Hp[(int64_t)(row < Mrows ? row : Mrows - 1) * ldh + col];
-    }
-  }
+  for (int ti = 0; ti < MI; ++ti)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = rbase + (r & 3) + 8 * (r >> 2);
-    float v = acc[r];
-    if (amask) {
-      // the forward stored dropped elements as -0.0f: the keep bit is the sign of a zero, no RNG replay needed
-      const bool keep = !dropon || (__float_as_uint(hv[r]) != 0x80000000u);
-      v *= act_mask_factor(hv[r], act, keep, dscale);
+    for (int tj = 0; tj < NI; ++tj) {
+      const int col = n0 + wn * 32 * NI + 32 * tj + (lane & 31);
+      const bool cok = col < Ncols;
+      const int colc = cok ? col : 0;
+      const int rbase = m0 + wm * 32 * MI + 32 * ti + 4 * (lane >> 5);
+      float hv[16];
+      if (amask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          hv[r] = Hp[(int64_t)(row < Mrows ? row : Mrows - 1) * ldh + colc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float v = acc_t[ti][tj][r];
+        if (amask) {
+          // the forward stored dropped elements as -0.0f: the keep bit is the sign of a zero, no RNG replay needed
+          const bool keep = !dropon || (__float_as_uint(hv[r]) != 0x80000000u);
+          v *= act_mask_factor(hv[r], act, keep, dscale);
+        }
+        if (cok && row < Mrows) C[(int64_t)row * ldc + col] = v;
+      }
     }
-    if (row < Mrows) C[(int64_t)row * ldc + col] = v;
-  }
   KT(9);
 }
 
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, int MI = 1, int NI = 1>
 static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
-  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI;
   int start = 0;
   int all_tiles = 0;
   for (int i = 0; i < gb.n; ++i) all_tiles += cdiv(gb.p[i].M, BM) * cdiv(gb.p[i].N, BN);
@@ -396,10 +419,10 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
     form = (form == -1 || form == f) ? f : 3;
   }
   switch (form) {
-    case 0: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 0>), dim3(start), dim3(256), 0, st, gb); break;
-    case 1: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 1>), dim3(start), dim3(256), 0, st, gb); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 2>), dim3(start), dim3(256), 0, st, gb); break;
-    default: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 3>), dim3(start), dim3(256), 0, st, gb); break;
+    case 0: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 0, MI, NI>), dim3(start), dim3(256), 0, st, gb); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 1, MI, NI>), dim3(start), dim3(256), 0, st, gb); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 2, MI, NI>), dim3(start), dim3(256), 0, st, gb); break;
+    default: hipLaunchKernelGGL((gemm_kernel<WM, WN, BK, 3, MI, NI>), dim3(start), dim3(256), 0, st, gb); break;
   }
   HMP_LAUNCH_CHECK();
   return HMP_OK;
@@ -419,7 +442,22 @@ int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   }
   // big problems (many tiles, or few tiles over a very deep K: the weight gradients of a 10^6-node graph): 64x64 tiles;
   // small ones: 32x32 tiles with in-block K split and deep K stages
-  if (tiles64 >= 1024 || work >= 1e9) return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
+  // 128x128 tiles (2x2 accumulator tiles per wave) once they still fill the chip: >= 256 of them, or a split-K launch (the
+  // K chunks supply the workgroups); HMP_GEMM_BIG=0 keeps the 64x64 form (tests compare the two)
+  if (tiles64 >= 1024 || work >= 1e9) {
+    int64_t tiles128 = 0;
+    for (int i = 0; i < gb.n; ++i) tiles128 += (int64_t)cdiv(gb.p[i].M, 128) * cdiv(gb.p[i].N, 128);
+    const char* gv = getenv("HMP_GEMM_BIG");
+    const bool big_ok = !(gv && gv[0] == '0');
+    // ... and only for wide outputs (every N >= 256): measured on MI355X, the GAT backward GEMMs (N = 512 .. 1100) gain 18 %
+    // (0.448 -> 0.366 ms per step, config 3), but at N = 192 / 65 (config 2 at batch 2048) the half-empty second column tile and
+    // two workgroups per CU instead of three LOSE 20 % (gemm 1.33 -> 1.67 ms)
+    int min_n = 1 << 30;
+    for (int i = 0; i < gb.n; ++i) min_n = gb.p[i].N < min_n ? gb.p[i].N : min_n;
+    if (big_ok && min_n >= 256 && work >= 1e9 && (tiles128 >= 256 || (want_split && max_k >= 8192)))
+      return launch_cfg<2, 2, 32, 2, 2>(gb, want_split, max_slabs, st);
+    return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
+  }
   if (max_k <= 64) return launch_cfg<1, 1, 64>(gb, want_split, max_slabs, st);
   return launch_cfg<1, 1, 128>(gb, want_split, max_slabs, st);
 }

@@ -297,3 +297,33 @@ def test_gemm_bf16_matches_bf16_rounded_inputs(M, N, K, ta, tb):
     Br = B.bfloat16().double()
     ref = (Ar.t() if ta else Ar) @ (Br.t() if tb else Br)
     torch.testing.assert_close(c.cpu().double(), ref, atol=2e-4 * (K ** 0.5) / 16 + 1e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
+def test_gemm_128x128_register_tiling_is_bit_identical_to_64x64(ta, tb, monkeypatch):
+    """Big problems (>= 256 tiles of 128x128, >= 1e9 MACs) take the 2x2-accumulator form of gemm_kernel: the k order of every
+    output element is unchanged, so the product is bit-identical to the 64x64 form (HMP_GEMM_BIG=0) -- and within fp32 round-off
+    of a float64 product.  NT (x W^T), NN (dZ W) and TN (dZ^T x) operand layouts, ragged edges."""
+    import ctypes as C
+
+    from hydra_gnn_amd import _lib
+
+    lib = _lib.require_device()
+    M, N, K = 16384 + 37, 384 + 5, 306
+    rng = np.random.default_rng(3)
+    a = torch.from_numpy(rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)).to(dev())
+    b = torch.from_numpy(rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)).to(dev())
+
+    def run():
+        c = torch.empty(M, N, dtype=torch.float32, device=dev())
+        _lib.check(lib.hmp_gemm_f32(a.data_ptr(), a.stride(0), ta, b.data_ptr(), b.stride(0), tb, c.data_ptr(), c.stride(0), M, N, K,
+                                    _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return c
+
+    big = run()
+    monkeypatch.setenv("HMP_GEMM_BIG", "0")
+    small = run()
+    assert torch.equal(big, small)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    torch.testing.assert_close(big.double(), ref, atol=2e-4, rtol=1e-5)  # |sum of 306 products of N(0,1)| ~ 17: 1e-5 relative
