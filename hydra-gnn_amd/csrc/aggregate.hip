@@ -21,6 +21,11 @@ __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; 
 constexpr int WIN_THREADS_CHAIN = 512;   // graph-local chain kernel: CHAIN_GROUPS groups of 256 threads (1024 threads would cap the
 constexpr int CHAIN_GROUPS = WIN_THREADS_CHAIN / 256;  // tile routines at 128 VGPRs: measured 1 201 spilled registers, 0.49 ms)
 
+// raw buffer descriptor over [base, base + bytes): loads past the end return 0 without touching memory
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
 // ----- row access helpers -----------------------------------------------------------------------
 // VEC = 4: 16-byte accesses (pointer and ld 16-byte aligned); VEC = 1: scalar fall-back for arbitrary ld.
 template <int VEC>
@@ -211,30 +216,76 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
   }
 }
 
+// ----- neighbour ids from the ELL table (kernels.h: ELL_W) ---------------------------------------------
+// The first 8 (PRE: 16) ids of `row`, requested by address arithmetic on the row alone: they travel in the same round trip as the
+// row extent.  Slots past the degree n were never written: they are replaced by the first id (a line the gather touches anyway;
+// the adds are masked by the callers exactly as for the clamped CSR loads), so every later load has a valid address.
+template <bool PRE>
+struct EllRow {
+  int4 h[PRE ? 4 : 2];
+  __device__ __forceinline__ void fetch(const int* __restrict__ ell, int row) {
+    const int4* p = reinterpret_cast<const int4*>(ell) + (int64_t)row * (ELL_W / 4);
+#pragma unroll
+    for (int q = 0; q < (PRE ? 4 : 2); ++q) h[q] = p[q];
+  }
+  __device__ __forceinline__ int word(int u) const {
+    const int4& v = h[u >> 2];
+    return (u & 3) == 0 ? v.x : (u & 3) == 1 ? v.y : (u & 3) == 2 ? v.z : v.w;
+  }
+  __device__ __forceinline__ void ids(int n, int (&j)[8], int (&jt)[PRE ? 8 : 1]) const {
+    const int first = n > 0 ? h[0].x : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      j[u] = u < n ? word(u) : first;
+      if constexpr (PRE) jt[u] = 8 + u < n ? word(8 + u) : first;
+    }
+  }
+};
+
 // ----- fused SAGE layer aggregation -----------------------------------------------------------------
 // out[t][i] = dropout(act( zroot[i] + bias + sum_e mean_{k in N_e(i)} z_e[col_k] ))   (one row group, result also in `tot`)
 template <int GS, int NV, bool ZB = false, bool HB = false>
 __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int c0, Acc<4> (&tot)[NV]) {
   constexpr int VEC = 4;
-  // dropout coordinates incl. the device step counter: read now, not behind the gathers (one dependent round trip less)
+  // Everything whose address depends on the row alone is requested here, and nothing of it is consumed before the gathers
+  // (a use inside one of these branches would put an s_waitcnt in it): the device step counter of the dropout coordinates, the
+  // root row and the bias, the row extents of every incoming edge type, the ELL ids of the first pair -- ONE round trip.
+  KT(3);
   DropCfg dcfg = D.drop;
-  if (D.drop_on) dcfg = drop_resolve(D.drop);
+  uint32_t step_add = 0;
+  if (D.drop_on) step_add = drop_step_vload(D.drop.step_dev);
+  Acc<VEC> bs[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c = c0 + q * GS * VEC;
     tot[q].zero();
+    bs[q].zero();
     if (c < D.F) {
       if (D.zroot) load_z<ZB>(tot[q], D.zroot, (int64_t)row * D.ldzr + D.roff + c);
-      if (D.bias) { Acc<VEC> b; b.load(D.bias + c); tot[q].add(b); }
+      if (D.bias) bs[q].load(D.bias + c);
     }
   }
-  // all row extents first: one round trip for every incoming edge type instead of one per type
   int rb[AGG_MAX_IN], re[AGG_MAX_IN];
 #pragma unroll
   for (int ii = 0; ii < AGG_MAX_IN; ++ii) {
     rb[ii] = re[ii] = 0;
     if (ii < D.n_in) { rb[ii] = D.in[ii].rowptr[row]; re[ii] = D.in[ii].rowptr[row + 1]; }
   }
+  constexpr bool ELLP = NV == 1 && GS < 64;  // the pair path below
+  EllRow<GS <= 16> hA, hB;
+  bool ell0 = false;
+  if constexpr (ELLP) {
+    const AggIn& A0 = D.in[0];
+    const AggIn& A1 = D.in[D.n_in > 1 ? 1 : 0];
+    ell0 = D.n_in > 0 && A0.ell && A1.ell;  // block-uniform
+    if (ell0) {
+      hA.fetch(A0.ell, row);
+      hB.fetch(A1.ell, row);
+    }
+  }
+  KTW(4);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) tot[q].add(bs[q]);  // (root + bias) first, as the sequential code
   if constexpr (NV == 1 && GS == 64) {
     // One wavefront per row (the caller made `row` wave-uniform): the neighbour ids of BOTH edge types of a pair are scalar
     // loads issued together, then 16 rows of the first type in flight, then 16 of the second through the same registers --
@@ -302,6 +353,14 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
       // per SIMD (config 4: 0.140 -> 0.151 ms).
       constexpr bool PRE = GS <= 16;
       int j0[UB], j1[UB], j0t[PRE ? UB : 1], j1t[PRE ? UB : 1];
+      if (ii == 0 ? ell0 : (I0.ell && I1.ell)) {  // block-uniform: ids by row address, no dependence on the extents
+        if (ii != 0) {
+          hA.fetch(I0.ell, row);
+          hB.fetch(I1.ell, row);
+        }
+        hA.ids(e0 - b0, j0, j0t);
+        hB.ids(e1 - b1, j1, j1t);
+      } else {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         j0[u] = I0.col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
@@ -311,14 +370,17 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
           j1t[u] = I1.col[e1 > b1 ? min(b1 + UB + u, e1 - 1) : 0];
         }
       }
+      }
       Acc<VEC> v0[UB], v1[UB];
       const bool cin = c0 < D.F;
       const int cc = cin ? c0 : 0;
+      if (ii == 0) KTW(5);
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         v0[u].load(I0.z + I0.coff + (int64_t)j0[u] * I0.ldz + cc);
         v1[u].load(I1.z + I1.coff + (int64_t)j1[u] * I1.ldz + cc);
       }
+      if (ii == 0) KTW(6);
       Acc<VEC> a0[1], a1[1];
       a0[0].zero();
       a1[0].zero();
@@ -368,6 +430,9 @@ __device__ __forceinline__ void agg_row(const AggDst& D, int mean, int row, int 
     for (int q = 0; q < NV; ++q) tot[q].add_div(acc[q], d);
   }
   }
+  KTW(7);
+  dcfg.step += step_add;
+  dcfg.step_dev = nullptr;
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c = c0 + q * GS * VEC;
@@ -436,7 +501,8 @@ __device__ __forceinline__ void ce_rowgroup(const AggDst& D, NetState* state, in
 template <int GS, int NV, bool ZB = false, bool HB = false>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   int ti = 0;
-  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
+  while (ti + 1 < a.n && (int)blockIdx.x >= a.bstart[ti + 1]) ++ti;
+  karg_warm<9>((int)offsetof(AggArgs, d) + ti * (int)sizeof(AggDst), (int)sizeof(AggDst));
   const AggDst& D = a.d[ti];
   const int rpb = 256 / GS;
   int local = blockIdx.x - D.block_start;
@@ -560,7 +626,8 @@ template <int GS>
 __global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
   __shared__ float Hs[256 * 17];
   int ti = 0;
-  while (ti + 1 < a.n && (int)blockIdx.x >= a.d[ti + 1].block_start) ++ti;
+  while (ti + 1 < a.n && (int)blockIdx.x >= a.bstart[ti + 1]) ++ti;
+  karg_warm<9>((int)offsetof(AggArgs, d) + ti * (int)sizeof(AggDst), (int)sizeof(AggDst));
   const AggDst& D = a.d[ti];
   agg_proj_tile<GS>(a, D, ((int)blockIdx.x - D.block_start) * 16, D.n_rows, true, Hs);
 }
@@ -597,6 +664,18 @@ __device__ __forceinline__ void agg_bwd_row(const TAggArgs& a, const TAggSrc& S,
     rb[oi] = re[oi] = 0;
     if (oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
   }
+  // ELL ids of the first pair in the round trip of the extents (see agg_row)
+  EllRow<GS <= 16> hA, hB;
+  bool ell0 = false;
+  if constexpr (NV == 1) {
+    const TAggOut& A0 = S.out[0];
+    const TAggOut& A1 = S.out[S.n_out > 1 ? 1 : 0];
+    ell0 = S.n_out > 0 && A0.t_ell && A1.t_ell;  // block-uniform
+    if (ell0) {
+      hA.fetch(A0.t_ell, row);
+      hB.fetch(A1.t_ell, row);
+    }
+  }
   // (the 16-wide scalar-id form of agg_row was measured here too: 6.94 -> 7.02 ms at config 5, not kept)
   if constexpr (NV == 1) {
     // outgoing edge types in PAIRS (see agg_row): ids of both, then 1/deg + gradient rows of both
@@ -612,6 +691,14 @@ __device__ __forceinline__ void agg_bwd_row(const TAggArgs& a, const TAggSrc& S,
       // GS <= 16: the ids of out-edges 8..15 travel with those of 0..7 (see agg_row): one round trip less for rows of 9..16 edges
       constexpr bool PRE = GS <= 16;
       int i0[UB], i1[UB], i0t[PRE ? UB : 1], i1t[PRE ? UB : 1];
+      if (oi == 0 ? ell0 : (O0.t_ell && O1.t_ell)) {  // block-uniform: ids by row address (see agg_row)
+        if (oi != 0) {
+          hA.fetch(O0.t_ell, row);
+          hB.fetch(O1.t_ell, row);
+        }
+        hA.ids(e0 - b0, i0, i0t);
+        hB.ids(e1 - b1, i1, i1t);
+      } else {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         i0[u] = O0.t_col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
@@ -620,6 +707,7 @@ __device__ __forceinline__ void agg_bwd_row(const TAggArgs& a, const TAggSrc& S,
           i0t[u] = O0.t_col[e0 > b0 ? min(b0 + UB + u, e0 - 1) : 0];
           i1t[u] = O1.t_col[e1 > b1 ? min(b1 + UB + u, e1 - 1) : 0];
         }
+      }
       }
       float d0[UB], d1[UB];
       Acc<VEC> v0[UB], v1[UB];
@@ -717,7 +805,8 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
     return;
   }
   int si = 0;
-  while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
+  while (si + 1 < a.n && (int)blockIdx.x >= a.bstart[si + 1]) ++si;
+  karg_warm<10>((int)offsetof(TAggArgs, s) + si * (int)sizeof(TAggSrc), (int)sizeof(TAggSrc));
   const TAggSrc& S = a.s[si];
   const int rpb = 256 / GS;
   int local = blockIdx.x - S.block_start;
@@ -758,6 +847,19 @@ __device__ __forceinline__ void agg_bwd_dx_tile(const TAggArgs& a, const TAggSrc
       rb[oi] = re[oi] = 0;
       if (live && oi < S.n_out) { rb[oi] = S.out[oi].t_rowptr[row]; re[oi] = S.out[oi].t_rowptr[row + 1]; }
     }
+    // ELL ids of the first pair in the round trip of the extents (see agg_row); a row past the end reads the tile's first row
+    const int erow = live ? row : row0;
+    EllRow<GS <= 16> hA, hB;
+    bool ell0 = false;
+    {
+      const TAggOut& A0 = S.out[0];
+      const TAggOut& A1 = S.out[S.n_out > 1 ? 1 : 0];
+      ell0 = S.n_out > 0 && A0.t_ell && A1.t_ell;  // block-uniform
+      if (ell0) {
+        hA.fetch(A0.t_ell, erow);
+        hB.fetch(A1.t_ell, erow);
+      }
+    }
     // outgoing edge types in PAIRS (see agg_row): ids of both, then 1/deg + gradient rows of both
     constexpr int UB = 8;
 #pragma unroll
@@ -771,6 +873,14 @@ __device__ __forceinline__ void agg_bwd_dx_tile(const TAggArgs& a, const TAggSrc
       // GS <= 16: the ids of out-edges 8..15 travel with those of 0..7 (see agg_row): one round trip less for rows of 9..16 edges
       constexpr bool PRE = GS <= 16;
       int i0[UB], i1[UB], i0t[PRE ? UB : 1], i1t[PRE ? UB : 1];
+      if (oi == 0 ? ell0 : (O0.t_ell && O1.t_ell)) {  // block-uniform: ids by row address (see agg_row)
+        if (oi != 0) {
+          hA.fetch(O0.t_ell, erow);
+          hB.fetch(O1.t_ell, erow);
+        }
+        hA.ids(e0 - b0, i0, i0t);
+        hB.ids(e1 - b1, i1, i1t);
+      } else {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         i0[u] = O0.t_col[e0 > b0 ? min(b0 + u, e0 - 1) : 0];
@@ -779,6 +889,7 @@ __device__ __forceinline__ void agg_bwd_dx_tile(const TAggArgs& a, const TAggSrc
           i0t[u] = O0.t_col[e0 > b0 ? min(b0 + UB + u, e0 - 1) : 0];
           i1t[u] = O1.t_col[e1 > b1 ? min(b1 + UB + u, e1 - 1) : 0];
         }
+      }
       }
       float d0[UB], d1[UB];
       Acc<VEC> v0[UB], v1[UB];
@@ -919,7 +1030,8 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     return;
   }
   int si = 0;
-  while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block_start) ++si;
+  while (si + 1 < a.n && (int)blockIdx.x >= a.bstart[si + 1]) ++si;
+  karg_warm<10>((int)offsetof(TAggArgs, s) + si * (int)sizeof(TAggSrc), (int)sizeof(TAggSrc));
   const TAggSrc& S = a.s[si];
   agg_bwd_dx_tile<GS>(a, S, ((int)blockIdx.x - S.block_start) * 16, S.n_rows, true, Hs);
 }
@@ -1114,9 +1226,7 @@ constexpr unsigned WIN_SKIP_OFF = 0xFFFFF000u;  // buffer offset beyond any reco
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // raw buffer over [base, base + bytes): an out-of-range offset reads as zero (no memory access) -- lets a batch of edges issue BOTH
 // an LDS read and a global read per edge without a branch: the one that does not apply is aimed at the zero row / out of range
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t win_rsrc(const void* base, unsigned bytes) { return buf_rsrc(base, bytes); }
 
 static_assert(AGG_MAX_IN == 6 && WG == 4, "sel_q / sel_root are written for 6 / 4 entries");
 struct WinFwd {
@@ -1667,6 +1777,13 @@ static int agg_win_out(const TAggSrc& S) {
   return -1;
 }
 
+// the compact copy of the entries' first blocks that the kernels search (AggArgs::bstart)
+static inline void sync_bstart(AggArgs& a) {
+  for (int i = 0; i < a.n; ++i) a.bstart[i] = a.d[i].block_start;
+}
+static inline void sync_bstart(TAggArgs& a) {
+  for (int i = 0; i < a.n; ++i) a.bstart[i] = a.s[i].block_start;
+}
 int agg_fwd_launch(AggArgs& a, hipStream_t st) {
   int Fmax = 0, blocks = 0;
   const int vec = 4;
@@ -1727,12 +1844,14 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
         a.total_blocks = blocks;
       }
     }
+    sync_bstart(a);
     if (a.hb16) hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true, true>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((agg_fwd_kernel<64, 1, true>), dim3(blocks), dim3(256), 0, st, a);
     HMP_LAUNCH_CHECK();
     return HMP_OK;
   }
   HMP_CHECK_ARG(!a.hb16, "agg_fwd: bf16 outputs need bf16 projected rows (the one-wavefront-per-row kernel)");
+  sync_bstart(a);
 #define LAUNCH_FWD(GS_, NV_) hipLaunchKernelGGL((agg_fwd_kernel<GS_, NV_>), dim3(blocks), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_FWD)
 #undef LAUNCH_FWD
@@ -1758,6 +1877,7 @@ int agg_proj_fwd_launch(AggArgs& a, hipStream_t st) {
   }
   a.total_blocks = blocks;
   if (blocks == 0) return HMP_OK;
+  sync_bstart(a);
   switch (gs) {
     case 16: hipLaunchKernelGGL((agg_proj_fwd_kernel<16>), dim3(blocks), dim3(256), 0, st, a); break;
     case 32: hipLaunchKernelGGL((agg_proj_fwd_kernel<32>), dim3(blocks), dim3(256), 0, st, a); break;
@@ -1831,12 +1951,14 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
         grid = blocks + (a.fin_row_lv ? 1 : 0);
       }
     }
+    sync_bstart(a);
     if (a.dzb16) hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true, true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((agg_bwd_kernel<64, 1, true, false>), dim3(grid), dim3(256), 0, st, a);
     HMP_LAUNCH_CHECK();
     return HMP_OK;
   }
   HMP_CHECK_ARG(!a.dzb16, "agg_bwd: a bf16 dz needs bf16 gradient rows (the one-wavefront-per-row kernel)");
+  sync_bstart(a);
 #define LAUNCH_BWD(GS_, NV_) hipLaunchKernelGGL((agg_bwd_kernel<GS_, NV_>), dim3(grid), dim3(256), 0, st, a)
   HMP_DISPATCH_GS_NV(gs, nv, LAUNCH_BWD)
 #undef LAUNCH_BWD
@@ -1867,6 +1989,7 @@ int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st) {
   if (blocks == 0 && !a.fin_row_lv) return HMP_OK;
   const int grid = blocks + (a.fin_row_lv ? 1 : 0);
   const size_t smem = (size_t)kmax * 17 * sizeof(float);
+  sync_bstart(a);
   switch (gs) {
     case 16: hipLaunchKernelGGL((agg_bwd_dx_kernel<16>), dim3(grid), dim3(256), smem, st, a); break;
     case 32: hipLaunchKernelGGL((agg_bwd_dx_kernel<32>), dim3(grid), dim3(256), smem, st, a); break;

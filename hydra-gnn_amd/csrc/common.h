@@ -47,6 +47,27 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int align4(int x) { return (x + 3) & ~3; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- kernel-argument warm-up ---------------------------------------------------------------------------------------
+// Kernel arguments are read through the scalar cache one 64-byte line at a time, and the compiler waits for every field where
+// it is first used: a workgroup that walks a 500-byte table entry of a by-value argument struct pays ~8 DEPENDENT misses
+// (0.28 us each on an idle MI355X, tools/microbench/kernarg_latency.hip) before its first gather load is issued.
+// karg_warm requests one word of every line of [off, off + bytes) of the kernel-argument segment back to back and waits
+// once: one round trip, after which the field reads hit the scalar cache.  (The loaded words are kept in registers until the
+// wait -- the compiler does not know these are loads, so it must not reuse their destinations earlier.)
+template <int LINES>
+__device__ __forceinline__ void karg_warm(int off, int bytes) {
+  const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  int t[LINES];
+#pragma unroll
+  for (int i = 0; i < LINES; ++i) {
+    const int o = (off + min(i * 64, bytes - 4)) & ~3;
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(t[i]) : "s"(kp), "s"(o));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < LINES; ++i) asm volatile("" ::"s"(t[i]));
+}
+
 // ---- in-kernel phase timestamps (profiling build only: make KTIME=1) -------------------------------------------
 // KT(i) stores the 100 MHz wall clock of thread 0 of block 0 into slot i of the translation unit's buffer;
 // hmp_debug_ktime_<tag>(out[64]) copies the buffer to the host.  Compiled out of the product library.
@@ -59,6 +80,12 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define KT(i)                                                                      \
   do {                                                                             \
     if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = wall_clock64();           \
+  } while (0)
+// stamp once every vector load issued so far has landed
+#define KTW(i)                                   \
+  do {                                           \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    KT(i);                                       \
   } while (0)
 // accumulating form: kt_buf[i] += now - t0 (t0 from KT_NOW()); thread 0 of block 0 only
 #define KT_NOW() wall_clock64()
@@ -74,6 +101,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define KT_DEFINE(tag)
 #define KT(i) \
   do {        \
+  } while (0)
+#define KTW(i) \
+  do {         \
   } while (0)
 #define KT_NOW() 0ull
 #define KT_ADD(i, t0) \
@@ -108,6 +138,15 @@ struct DropCfg {
   float scale;          // 1/(1-p)
   const int* step_dev;  // ... plus *step_dev when set (device step counter: fresh masks under graph replay)
 };
+
+// The device step counter through the VECTOR memory path.  A scalar load of it costs a kernel its first memory round trip on its
+// own: scalar loads return out of order, so the next s_waitcnt lgkmcnt(0) -- in front of the first kernel-argument field read
+// after it -- waits for the counter too, before any gather load is issued.  The vector load is waited for where the value is
+// used (the dropout epilogue, behind the gathers).  A null pointer reads 0 through a descriptor of zero records.
+__device__ __forceinline__ uint32_t drop_step_vload(const int* step_dev) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(step_dev), 0, step_dev ? 4 : 0, 0x00020000);
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 0);
+}
 
 __device__ inline DropCfg drop_resolve(DropCfg c) {
   if (c.step_dev) c.step += (uint32_t)(*c.step_dev);

@@ -181,6 +181,8 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
     J.rowptr = wsi + F.rowptr; J.col = wsi + F.col; J.eid = wsi + F.eid;
     J.t_rowptr = wsi + F.t_rowptr; J.t_col = wsi + F.t_col; J.t_pos = nullptr;
     J.degf = reinterpret_cast<float*>(wsi + F.degf);
+    J.ell = F.ell ? wsi + F.ell : nullptr;
+    J.t_ell = F.t_ell ? wsi + F.t_ell : nullptr;
     J.cnt_in = J.cnt_out = J.cur_in = J.cur_out = nullptr;
     J.tmpc_in = J.tmpc_out = nullptr;
     J.tmp_in = wsi + F.tmp_in; J.tmp_out = wsi + F.tmp_out; J.t_eid = wsi + F.t_eid; J.pos_of_eid = wsi + F.pos_of_eid;

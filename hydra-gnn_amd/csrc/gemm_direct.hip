@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_direct_kernel(const TnBatch tb
   __shared__ float red[4 * 16 * 64];
   const int blk = blockIdx.x;
   KT(8);
+  // the whole problem table in one round trip (the search below walks one argument line per problem otherwise: common.h)
+  karg_warm<(sizeof(TnBatch) + 63) / 64>(0, (int)sizeof(TnBatch));
   int pi = 0;
   while (pi + 1 < tb.n && blk >= tb.p[pi + 1].tile_start) ++pi;
   const TnProblem& P = tb.p[pi];

@@ -70,6 +70,7 @@ struct FrontJob {    // one edge type of the plan; arrays as 4-byte-word offsets
   const int64_t* ei;
   int E, n_src, n_dst;
   uint32_t rowptr, col, eid, t_rowptr, t_col, t_eid, tmp_in, tmp_out, pos_of_eid, degf;
+  uint32_t ell, t_ell;  // 0: none
 };
 struct PackSeg;
 struct NetState;
@@ -119,6 +120,7 @@ struct PlanJob {
   int n_src, n_dst;
   int *rowptr, *col, *eid, *t_rowptr, *t_col, *t_pos;
   float* degf;  // optional [n_dst]: 1 / max(in-degree, 1) as float
+  int *ell, *t_ell;  // optional [n_dst][ELL_W] / [n_src][ELL_W]: first ids of every row; written by the single-launch build only
   // scratch
   int *cnt_in, *cnt_out, *cur_in, *cur_out;  // must be zero on entry (one contiguous block); left zero on exit
   int *tmp_in, *tmp_out, *t_eid, *pos_of_eid;
@@ -128,6 +130,7 @@ struct PlanBatch {
   int n;
   int need_tpos;   // build t_pos (only GAT's source-major backward reads it)
   int clear_first; // memset the counters before the launch (caller-provided scratch of unknown content)
+  int built_small; // out: plan_launch took the single-launch build (the one that also writes PlanJob::ell / t_ell)
   int64_t edge_start[HMP_MAX_EDGE_TYPES + 1];
   int64_t row_start[2 * HMP_MAX_EDGE_TYPES + 1];  // rows of (job, dir): dir 0 = by dst, 1 = by src
   PlanJob j[HMP_MAX_EDGE_TYPES];
@@ -141,6 +144,10 @@ int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st);
 // K1 + fused SAGE aggregation
 // ---------------------------------------------------------------------------------------------
 constexpr int AGG_MAX_IN = 6;
+// Neighbour-id table in ELL form next to the CSR arrays: row r's first ELL_W ids at ell[r * ELL_W ..] (slots past the row's degree
+// are NOT written).  Its address depends on the row alone, so the small-batch aggregation kernels request it together with the
+// row extent -- extents+ids, rows: two dependent round trips where the CSR form needs three (extents, ids, rows).
+constexpr int ELL_W = 16;
 struct AggIn {
   const int* rowptr;
   const int* col;
@@ -148,6 +155,7 @@ struct AggIn {
   int ldz, coff;
   int same_type;   // source node type == destination node type (one index space): candidate for the LDS-windowed gather
   int n_src;       // rows of z
+  const int* ell;  // [n_dst][ELL_W] first neighbour ids of every row (single-launch plan by-product, see plan_small.h), or null
 };
 struct AggDst {
   int n_rows, F;
@@ -185,6 +193,8 @@ struct AggArgs {
   int hb16;  // with zb16: the outputs (AggDst::out) are WRITTEN as bf16 elements too (activations of a hidden layer, read only by GEMMs)
   int win_R, win_W;  // LDS-windowed launch (agg_fwd_win_kernel): destination rows per workgroup / source rows staged
   NetState* state;  // status bits (fused cross entropy: label out of range)
+  int bstart[HMP_MAX_NODE_TYPES];  // d[i].block_start again, in the struct's first lines (filled by the launchers): a workgroup
+                                   // finds its entry without touching one argument line per entry, see karg_warm (common.h)
   AggDst d[HMP_MAX_NODE_TYPES];
 };
 int agg_fwd_launch(AggArgs& a, hipStream_t st);
@@ -200,6 +210,7 @@ struct TAggOut {
   int ldg, coff, F;
   int same_type;      // destination node type == source node type: candidate for the LDS-windowed gather
   int n_dst;          // rows of g
+  const int* t_ell;   // [n_src][ELL_W] first out-neighbour ids of every row, or null (see AggIn::ell)
 };
 struct TAggSrc {
   int n_rows;
@@ -232,6 +243,7 @@ struct TAggArgs {
   int fin_rows;
   float* fin_out2;
   NetState* fin_state;
+  int bstart[HMP_MAX_NODE_TYPES];  // s[i].block_start again (as AggArgs::bstart)
   TAggSrc s[HMP_MAX_NODE_TYPES];
 };
 int agg_bwd_launch(TAggArgs& a, hipStream_t st);

@@ -91,6 +91,10 @@ struct hmp_net {
   char* ws_base = nullptr;
   size_t ws_bytes = 0;
   float* degf[HMP_MAX_EDGE_TYPES];  // 1 / max(in-degree,1) per destination node, by-product of the plan
+  int* ell[HMP_MAX_EDGE_TYPES];     // [n_dst][ELL_W] / [n_src][ELL_W] first neighbour ids per row (kernels.h), by-product of
+  int* t_ell[HMP_MAX_EDGE_TYPES];   // the single-launch plan build only: valid while ell_ok
+  bool ell_ok = false;
+  bool ell_on = false;              // this call: HMP_ELL=1
   float* d_row_lv = nullptr;        // per output row {loss, valid} of the fused step's loss kernel
   bool fin_loss = false;            // the next gradient un-pack also finalises {loss_sum, count}
 
@@ -514,6 +518,8 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
     P.d_t_pos = (int32_t*)take((size_t)ce[e] * 4);
     n->plan_scratch[e] = (int*)take(plan_scratch_ints(ce[e], ns, nd) * 4);
     n->degf[e] = (float*)take((size_t)nd * 4);
+    n->ell[e] = (int*)take((size_t)nd * ELL_W * 4);
+    n->t_ell[e] = (int*)take((size_t)ns * ELL_W * 4);
   }
   n->d_packed = (float*)take((size_t)n->packed_floats * 4);
   n->d_slabs = (float*)take((size_t)n->slab_floats * 4);
@@ -718,6 +724,8 @@ int check_batch(const hmp_net* n, const hmp_batch* b) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------
+// the ELL id tables of the current plan may be read (HMP_ELL=0: never -- the CSR-only gathers, for tests and A/B runs)
+bool ell_use(const hmp_net* n) { return n->ell_on && n->ell_ok; }
 void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb) {
   memset(&pb, 0, sizeof(pb));
   pb.n = n->ET;
@@ -734,6 +742,8 @@ void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb) {
     J.E = P.n_edges; J.n_src = P.n_src; J.n_dst = P.n_dst;
     J.rowptr = P.d_rowptr; J.col = P.d_col; J.eid = P.d_eid;
     J.t_rowptr = P.d_t_rowptr; J.t_col = P.d_t_col; J.t_pos = P.d_t_pos;
+    J.ell = n->ell_on ? n->ell[e] : nullptr;
+    J.t_ell = n->ell_on ? n->t_ell[e] : nullptr;
     plan_carve(J, n->plan_scratch[e]);
   }
 }
@@ -742,7 +752,9 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
   Scope sc(n, KC_PLAN, st);
   PlanBatch pb;
   fill_plan_batch(n, b, pb);
-  return plan_launch(pb, &n->d_state->status, st);
+  const int rc = plan_launch(pb, &n->d_state->status, st);
+  n->ell_ok = rc == HMP_OK && pb.built_small != 0 && n->ell_on;
+  return rc;
 }
 
 // Small (launch-latency-bound) batches (<= 65 536 nodes): the row-local GEMM that follows an aggregation (next layer's projection in the
@@ -875,6 +887,8 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
     F.rowptr = woff(J.rowptr); F.col = woff(J.col); F.eid = woff(J.eid);
     F.t_rowptr = woff(J.t_rowptr); F.t_col = woff(J.t_col); F.t_eid = woff(J.t_eid);
     F.tmp_in = woff(J.tmp_in); F.tmp_out = woff(J.tmp_out); F.pos_of_eid = woff(J.pos_of_eid); F.degf = woff(J.degf);
+    F.ell = J.ell ? woff(J.ell) : 0u;
+    F.t_ell = J.t_ell ? woff(J.t_ell) : 0u;
   }
   fa.status = &n->d_state->status;
   // ---- pack blocks
@@ -1007,6 +1021,10 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   hipStream_t side = (n->use_branches && (n->branch_mask & 1)) ? n->side[0] : main_st;
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   n->fuse_now = fuse_small(n, b);
+  {
+    const char* v = getenv("HMP_ELL");  // 1: neighbour ids from the plan's ELL tables (measured slower, see kernels.h: off by default)
+    n->ell_on = v && v[0] == '1';
+  }
   memset(n->h16, 0, sizeof(n->h16));
   n->reuse_plan = false;
   if (b->plan_valid) {
@@ -1024,6 +1042,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   if (front) {
     Scope sc(n, KC_FRONT, main_st);
     HMP_TRY(front_launch(fa, main_st));
+    if (fa.plan_blocks > 0) n->ell_ok = n->ell_on;  // the front kernel's plan role is the single-launch build
     for (int e = 0; e < n->ET; ++e) {  // what run_plan records on the host
       hmp_plan& P = n->plan[e];
       P.n_src = b->n_nodes[S.edge_src[e]]; P.n_dst = b->n_nodes[S.edge_dst[e]]; P.n_edges = b->n_edges[e];
@@ -1125,6 +1144,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           I.z = n->Z[l][C.src]; I.ldz = Y.ncols[C.src]; I.coff = Y.conv[c].coff;
           I.same_type = C.src == C.dst ? 1 : 0;
           I.n_src = b->n_nodes[C.src];
+          I.ell = ell_use(n) ? n->ell[C.edge_type] : nullptr;
         }
       }
       // fuse the projection of layer l+1 when every node type it reads is produced right here
@@ -1303,6 +1323,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           O.ldg = ldg; O.coff = Y.conv[c].coff; O.F = fpad(C.f_out);
           O.same_type = C.src == C.dst ? 1 : 0;
           O.n_dst = b->n_nodes[C.dst];
+          O.t_ell = ell_use(n) ? n->t_ell[C.edge_type] : nullptr;
         }
       }
       // input gradient of layer l inside the same kernel (row-local GEMM on 16-row tiles) for small batches
@@ -1632,6 +1653,7 @@ extern "C" int hmp_net_bind_workspace(hmp_net* n, void* d_workspace, size_t byte
   n->bound = true;
   n->have_fwd = false;
   n->plan_ok = false;
+  n->ell_ok = false;
   return HMP_OK;
 }
 

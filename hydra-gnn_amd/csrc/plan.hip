@@ -322,7 +322,9 @@ int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
   const int64_t rows = pb.row_start[2 * pb.n];
   const char* sm = getenv("HMP_PLAN_SMALL");  // 0 / 1 pins the multi-launch / single-launch build (tests); unset: by size
   const int small_mode = sm ? (sm[0] == '1' ? 1 : 0) : -1;
+  pb.built_small = 0;
   if (small_mode == 1 || (small_mode < 0 && E <= PS_MAX_EDGES)) {
+    pb.built_small = 1;
     PlanSmallArgs a;
     a.pb = pb;
     const int blocks = plan_small_layout(pb, a.part_start, a.rows_per_part);

@@ -144,6 +144,7 @@ __device__ __forceinline__ void plan_small_part(const PlanJob& J, int dir, int p
   const int total = s_total;
   const bool in_lds = total <= PS_TMP;
   int* __restrict__ gtmp = (dir ? J.tmp_out : J.tmp_in) + base;
+  int* __restrict__ ell = dir ? J.t_ell : J.ell;  // first ELL_W ids of every row, next to the CSR arrays (kernels.h)
   // pass 2: every edge of the part takes a slot in its row
   if constexpr (RC) {
 #pragma unroll
@@ -206,6 +207,7 @@ __device__ __forceinline__ void plan_small_part(const PlanJob& J, int dir, int p
         if (need_tpos) J.t_eid[pos] = mine;
         J.t_col[pos] = lcol[q];
       }
+      if (ell && rank < ELL_W) ell[(int64_t)(r0 + r) * ELL_W + rank] = lcol[q];
     }
   } else {
     for (int q = tid; q < total; q += 1024) {
@@ -227,6 +229,7 @@ __device__ __forceinline__ void plan_small_part(const PlanJob& J, int dir, int p
         if (need_tpos) J.t_eid[pos] = mine;
         J.t_col[pos] = (int)ed[mine];
       }
+      if (ell && rank < ELL_W) ell[(int64_t)(r0 + lo) * ELL_W + rank] = (int)(dir ? ed[mine] : es[mine]);
     }
   }
 }

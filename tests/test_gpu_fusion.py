@@ -529,3 +529,37 @@ def test_graph_local_chain_is_skipped_without_graph_boundaries(monkeypatch):
     _lib.check(nat._lib.hmp_net_profile(nat._handle, 0))
     launches = dict(zip(_lib.KCLASS_NAMES, list(ln)))
     assert launches["chain"] == 0 and launches["aggregate_fwd"] == 3
+
+
+@pytest.mark.parametrize("kw_over,n_graphs,train", [({}, 8, False), ({}, 64, True), ({"hidden_dim": 128, "num_layers": 4}, 8, False),
+                                                    ({"hidden_dim": 32, "num_layers": 2}, 5, False)])
+def test_ell_id_table_gathers_are_bit_identical(monkeypatch, kw_over, n_graphs, train):
+    """HMP_ELL=0: the fused aggregation kernels take neighbour ids from the CSR arrays (extents, ids, rows); default: the first
+    16 ids of every row come from the plan's ELL table in the round trip of the extents.  Same ids, same order of additions:
+    predictions, gradients and three optimiser steps are bit-identical.  config 2 batches hold rows on both sides of the
+    16-id table width (rooms with > 16 objects take the CSR tail)."""
+    kw = dict(SAGE_KW, **kw_over)
+    if train:
+        kw["dropout"] = 0.25
+    batch = workloads.config2_batch(n_graphs)
+    deg = torch.bincount(batch["objects", "objects_to_rooms", "rooms"].edge_index[1])
+    assert int(deg.max()) > 16 and int(deg.min()) < 16
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HMP_ELL", mode)
+        with fuse_env("1"):
+            _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+            res[mode] = run_fwd_bwd(net, batch, "rooms", train=train)
+            step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, use_graph=False)
+            gb = batch.to(DEV)
+            for _ in range(3):
+                step(gb, gb["rooms"].y)
+            res[mode] += (step.loss(), {k: p.detach().clone() for k, p in net.named_parameters()})
+    monkeypatch.delenv("HMP_ELL")
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g in res["0"][2].items():
+        if g is not None:
+            assert torch.equal(res["1"][2][k], g), k
+    assert res["1"][3] == res["0"][3]
+    for k, p0 in res["0"][4].items():
+        assert torch.equal(res["1"][4][k], p0), k

@@ -49,6 +49,7 @@ def main():
     lib = _lib.load()
     a = read(lib, "agg")
     show("agg_proj_fwd l1 (blk0)", a, [0, 1, 2])
+    show("agg_row (last fwd launch)", a, [3, 4, 5, 6, 7])
     show("agg_bwd_dx l1 (blk0)", a, [8, 9, 10])
     show("front gemm tile (blk0)", read(lib, "front"), [0, 1])
     show("gemm_tn_direct dW (blk0)", read(lib, "gemmd"), [8, 9])
