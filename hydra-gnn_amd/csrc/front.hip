@@ -15,19 +15,33 @@
 //   then pack blocks   16 (packed row, 64-column chunk) items per block
 // The step's critical path sees max(projection, plan) ~ 20 us instead of their sum.
 #include "device_fns.h"
+#ifdef HMP_KTIME
+// phase stamps of the FIRST plan part (job 0, by destination, part 0) into this file's stamp buffer
+#define PS_KT(i)                                                                           \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && part == 0 && dir == 0 && J.ei == front_kt_ei) front_kt_slot(i); \
+  } while (0)
+namespace hmp {
+__device__ const void* front_kt_ei;
+__device__ void front_kt_slot(int i);
+}
+#endif
 #include "plan_small.h"
 
 namespace hmp {
 
 KT_DEFINE(front)
+#ifdef HMP_KTIME
+__device__ void front_kt_slot(int i) { kt_buf[i] = wall_clock64(); }
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int FT = 64;         // tile edge
 constexpr int FBK = 128;       // K stage
-constexpr int FLD = FT + 4;    // LDS row pitch of a [k][row] image
+constexpr int FLD = FBK + 2;    // LDS pitch (floats) of a [row][k] image: 8-byte aligned rows, row m starts in bank 2m mod 32
 constexpr int FSTAGES = 3;     // K <= 384
-constexpr int F_STAGE_FLOATS = 2 * FBK * FLD;
+constexpr int F_STAGE_FLOATS = 2 * 2 * FT * FLD;  // two buffers (the stages alternate) of an A and a B image
 constexpr int F_RED_FLOATS = 16 * 16 * 64;
 constexpr int F_GEMM_FLOATS = F_STAGE_FLOATS > F_RED_FLOATS ? F_STAGE_FLOATS : F_RED_FLOATS;
 constexpr int F_SEG_OFF = F_GEMM_FLOATS * 4;  // byte offset of the segment table copy (behind the stage / reduction area)
@@ -45,7 +59,7 @@ __device__ __forceinline__ float4 fr_ld4(const float* p, bool second_ok) {
 template <int VEC, int NSRC>
 __device__ __forceinline__ void front_gemm_tile(const FrontProb& P, const FrontSeg* __restrict__ sseg, const float* __restrict__ params,
                                                 int tm, int tn, float* lds) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = tm * FT, n0 = tn * FT;
   // slot geometry: slot q = tid + i * 1024 (i < 2) covers row q >> 5, k4 = (q & 31) * 4 of a 64 x 128 stage
   const int k4 = (tid & 31) * 4;
@@ -90,40 +104,68 @@ __device__ __forceinline__ void front_gemm_tile(const FrontProb& P, const FrontS
       rb[s][i] = make_float4(klive && bl ? b.x : 0.f, m1 && bl ? b.y : 0.f, m2 && bl ? b.z : 0.f, m3 && bl ? b.w : 0.f);
     }
   }
+  KT(2);
+  KTW(3);
   // ---- stages through LDS -----------------------------------------------------------------------------------------
-  float* As = lds;
-  float* Bs = lds + FBK * FLD;
+  // [row][k] images, two buffers: stage s + 1 is written while the MFMAs of stage s run (one barrier per stage; written and read
+  // in turn -- write, barrier, MFMA, barrier -- a stage cost 2.8 us of which the MFMAs were 1.0).  A thread's four k values of a
+  // row are two 8-byte writes; an MFMA operand (row m = lane & 31, k + (lane >> 5)) is a 4-byte read at a constant offset from
+  // the lane's row base (pitch 130 floats: rows 16 apart share a bank, a 2-way conflict on the 32 reads of a stage).
   const int kg = w >> 2, sub = w & 3, wm = sub & 1, wn = sub >> 1;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-  for (int s = 0; s < FSTAGES; ++s) {
-    if (s >= n_stage) break;  // block-uniform
-    // [k][row] image, row rotated by k/4 so that the 32 lanes of a row (k = 0, 4, 8, ..) hit 32 different banks
+  auto put = [&](int s) {
+    float* As = lds + (s & 1) * (2 * FT * FLD);
+    float* Bs = As + FT * FLD;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (tid >> 5) + 32 * i;
-      const int rr = (row + (k4 >> 2)) & (FT - 1);
-      As[(k4 + 0) * FLD + rr] = ra[s][i].x; As[(k4 + 1) * FLD + rr] = ra[s][i].y;
-      As[(k4 + 2) * FLD + rr] = ra[s][i].z; As[(k4 + 3) * FLD + rr] = ra[s][i].w;
-      Bs[(k4 + 0) * FLD + rr] = rb[s][i].x; Bs[(k4 + 1) * FLD + rr] = rb[s][i].y;
-      Bs[(k4 + 2) * FLD + rr] = rb[s][i].z; Bs[(k4 + 3) * FLD + rr] = rb[s][i].w;
+      float2* pa = reinterpret_cast<float2*>(As + row * FLD + k4);
+      float2* pb = reinterpret_cast<float2*>(Bs + row * FLD + k4);
+      pa[0] = make_float2(ra[s][i].x, ra[s][i].y); pa[1] = make_float2(ra[s][i].z, ra[s][i].w);
+      pb[0] = make_float2(rb[s][i].x, rb[s][i].y); pb[1] = make_float2(rb[s][i].z, rb[s][i].w);
     }
-    __syncthreads();
-    const int klen = min(FBK, P.K - s * FBK);
-    const int ma = wm * 32 + (lane & 31), mb = wn * 32 + (lane & 31);
+  };
+  put(0);
+  KT(5);
+  __syncthreads();
+  KT(6);
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
-      const int kb = kg * 32 + kk;
-      if (kb < klen) {  // wave-uniform: skip k rows that are all zero (ragged last stage)
-        const int k = kb + (lane >> 5);
-        const int rot = kb >> 2;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * FLD + ((ma + rot) & (FT - 1))], Bs[k * FLD + ((mb + rot) & (FT - 1))], acc, 0, 0, 0);
+  for (int s = 0; s < FSTAGES; ++s) {
+    if (s >= n_stage) break;  // block-uniform
+    if (s + 1 < FSTAGES && s + 1 < n_stage) put(s + 1);
+    const float* As = lds + (s & 1) * (2 * FT * FLD);
+    const float* Bs = As + FT * FLD;
+    const int klen = min(FBK, P.K - s * FBK);
+    // k steps of this wave's K-group inside the stage (wave-uniform; a ragged last stage leaves some groups short or idle)
+    const int nk = min(max(klen - kg * 32, 0), 32);
+    const float* ap = As + (wm * 32 + (lane & 31)) * FLD + kg * 32 + (lane >> 5);
+    const float* bp = Bs + (wn * 32 + (lane & 31)) * FLD + kg * 32 + (lane >> 5);
+    if (nk == 32) {
+      // full group: operand reads in batches of 8 steps ahead of the MFMAs that consume them (a branch per step, as the ragged
+      // form below needs, makes every step wait for its own two LDS reads)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          av[i] = ap[16 * h + 2 * i];
+          bv[i] = bp[16 * h + 2 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
       }
+    } else {
+      for (int kk = 0; kk < nk; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
     }
+    if (s == 0) KT(7);
+    if (s == 1) KT(14);
     __syncthreads();
+    if (s == 0) KT(13);
+    if (s == 1) KT(15);
   }
+  KT(4);
   // ---- fixed-order sum over the 4 K-groups; wave (kg, sub) finishes accumulator registers 4 kg .. 4 kg + 3 -----------
   float* red = lds;
 #pragma unroll
@@ -181,11 +223,15 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
     J.rowptr = wsi + F.rowptr; J.col = wsi + F.col; J.eid = wsi + F.eid;
     J.t_rowptr = wsi + F.t_rowptr; J.t_col = wsi + F.t_col; J.t_pos = nullptr;
     J.degf = reinterpret_cast<float*>(wsi + F.degf);
+    J.gp_dst = F.gp_dst; J.gp_src = F.gp_src; J.gp_edge = F.gp_edge; J.n_graphs = F.n_graphs;
     J.ell = F.ell ? wsi + F.ell : nullptr;
     J.t_ell = F.t_ell ? wsi + F.t_ell : nullptr;
     J.cnt_in = J.cnt_out = J.cur_in = J.cur_out = nullptr;
     J.tmpc_in = J.tmpc_out = nullptr;
     J.tmp_in = wsi + F.tmp_in; J.tmp_out = wsi + F.tmp_out; J.t_eid = wsi + F.t_eid; J.pos_of_eid = wsi + F.pos_of_eid;
+#ifdef HMP_KTIME
+    if (threadIdx.x == 0 && pb == 0) front_kt_ei = a.job[0].ei;
+#endif
     const bool last = pb + 1 == a.part_start[jd + 1];
     if (a.plan_rc) plan_small_part<true>(J, jd & 1, pb - a.part_start[jd], a.rows_per_part[jd], last, a.need_tpos, a.status, lds);
     else plan_small_part<false>(J, jd & 1, pb - a.part_start[jd], a.rows_per_part[jd], last, a.need_tpos, a.status, lds);

@@ -71,6 +71,8 @@ struct FrontJob {    // one edge type of the plan; arrays as 4-byte-word offsets
   int E, n_src, n_dst;
   uint32_t rowptr, col, eid, t_rowptr, t_col, t_eid, tmp_in, tmp_out, pos_of_eid, degf;
   uint32_t ell, t_ell;  // 0: none
+  const int64_t *gp_dst, *gp_src, *gp_edge;  // as PlanJob
+  int n_graphs;
 };
 struct PackSeg;
 struct NetState;
@@ -121,6 +123,10 @@ struct PlanJob {
   int *rowptr, *col, *eid, *t_rowptr, *t_col, *t_pos;
   float* degf;  // optional [n_dst]: 1 / max(in-degree, 1) as float
   int *ell, *t_ell;  // optional [n_dst][ELL_W] / [n_src][ELL_W]: first ids of every row; written by the single-launch build only
+  // optional (all three or none; single-launch build only): the batch is a union of n_graphs graphs whose edges are listed graph
+  // by graph -- int64 [n_graphs + 1] row offsets of the destination / source node type and edge offsets (hmp_batch::d_edge_ptr)
+  const int64_t *gp_dst, *gp_src, *gp_edge;
+  int n_graphs;
   // scratch
   int *cnt_in, *cnt_out, *cur_in, *cur_out;  // must be zero on entry (one contiguous block); left zero on exit
   int *tmp_in, *tmp_out, *t_eid, *pos_of_eid;

@@ -742,6 +742,14 @@ void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb) {
     J.E = P.n_edges; J.n_src = P.n_src; J.n_dst = P.n_dst;
     J.rowptr = P.d_rowptr; J.col = P.d_col; J.eid = P.d_eid;
     J.t_rowptr = P.d_t_rowptr; J.t_col = P.d_t_col; J.t_pos = P.d_t_pos;
+    {  // graph-sorted edge list vouched for by the caller (hmp_batch::d_edge_ptr)
+      const int ts = n->spec.edge_src[e], td = n->spec.edge_dst[e];
+      const char* sv = getenv("HMP_PLAN_SLICED");  // 0: read the whole edge list per part (tests compare both builds)
+      const bool on = !(sv && sv[0] == '0');
+      if (on && b->n_graphs > 0 && b->d_edge_ptr[e] && b->d_node_ptr[ts] && b->d_node_ptr[td]) {
+        J.gp_edge = b->d_edge_ptr[e]; J.gp_src = b->d_node_ptr[ts]; J.gp_dst = b->d_node_ptr[td]; J.n_graphs = b->n_graphs;
+      }
+    }
     J.ell = n->ell_on ? n->ell[e] : nullptr;
     J.t_ell = n->ell_on ? n->t_ell[e] : nullptr;
     plan_carve(J, n->plan_scratch[e]);
@@ -887,6 +895,7 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
     F.rowptr = woff(J.rowptr); F.col = woff(J.col); F.eid = woff(J.eid);
     F.t_rowptr = woff(J.t_rowptr); F.t_col = woff(J.t_col); F.t_eid = woff(J.t_eid);
     F.tmp_in = woff(J.tmp_in); F.tmp_out = woff(J.tmp_out); F.pos_of_eid = woff(J.pos_of_eid); F.degf = woff(J.degf);
+    F.gp_dst = J.gp_dst; F.gp_src = J.gp_src; F.gp_edge = J.gp_edge; F.n_graphs = J.n_graphs;
     F.ell = J.ell ? woff(J.ell) : 0u;
     F.t_ell = J.t_ell ? woff(J.t_ell) : 0u;
   }

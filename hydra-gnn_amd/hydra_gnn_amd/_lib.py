@@ -82,6 +82,7 @@ class Batch(C.Structure):
         ("d_node_ptr", C.c_void_p * MAX_NODE_TYPES),
         ("n_graphs", C.c_int32),
         ("max_graph_nodes", C.c_int32),
+        ("d_edge_ptr", C.c_void_p * MAX_EDGE_TYPES),
     ]
 
 

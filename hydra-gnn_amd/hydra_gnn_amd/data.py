@@ -91,6 +91,13 @@ class _Store:
         object.__getattribute__(self, "_d")[name] = value
         object.__setattr__(self, "_v", object.__getattribute__(self, "_v") + 1)
 
+    def __delattr__(self, name):
+        d = object.__getattribute__(self, "_d")
+        if name not in d:
+            raise AttributeError(name)
+        del d[name]
+        object.__setattr__(self, "_v", object.__getattribute__(self, "_v") + 1)
+
     def __contains__(self, name):
         return name in object.__getattribute__(self, "_d")
 
@@ -257,6 +264,12 @@ def collate(graphs: Sequence[HeteroData]) -> HeteroData:
             shift = torch.tensor([[offsets[src][gi]], [offsets[dst][gi]]], dtype=ei.dtype)
             parts.append(ei + shift)
         out[et].edge_index = torch.cat(parts, dim=1)
+        # edges of graph g are entries [ptr[g], ptr[g+1]) (what [PyG] keeps in Batch._slice_dict): lets the plan build of a
+        # small batch read, per block of rows, only the edges of the graphs that own them (hmp_batch::d_edge_ptr)
+        eoff = [0]
+        for q in parts:
+            eoff.append(eoff[-1] + q.size(1))
+        out[et].ptr = torch.tensor(eoff, dtype=torch.int64)
         if "edge_attr" in graphs[0][et]:
             out[et].edge_attr = torch.cat([g[et].edge_attr for g in graphs], dim=0)
     # host knowledge of the collation: lets the engine run the per-graph phases of a training step as one launch (hmp_batch)

@@ -330,6 +330,13 @@ class NativeNet:
                 h.c.d_node_ptr[i] = p.data_ptr()
         h.c.n_graphs = ng
         h.c.max_graph_nodes = mg if ng else 0
+        if ng:  # graph-sorted edge lists (collate's per-edge-type ptr)
+            for i, e in enumerate(self.edge_types):
+                st_ = data[e] if e in data.edge_types else None
+                p = getattr(st_, "ptr", None) if st_ is not None else None
+                if p is not None and p.is_cuda and p.dtype == torch.int64 and p.is_contiguous() and p.numel() == ng + 1:
+                    h.keep.append(p)
+                    h.c.d_edge_ptr[i] = p.data_ptr()
         if labels is not None:
             _require_cuda(labels, "labels")
             lab = labels.to(torch.int64).contiguous()

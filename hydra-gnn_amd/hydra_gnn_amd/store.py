@@ -241,6 +241,8 @@ class BatchStream:
         hd.keep = list(self._bufs) + [self._offsets]
         for i, t in enumerate(nat.node_types):
             hd.c.d_node_ptr[i] = self._offsets.data_ptr() + 8 * slot_of[t] * self._off_stride
+        for i, e in enumerate(nat.edge_types):  # the collator's edge offsets: edges arrive graph by graph
+            hd.c.d_edge_ptr[i] = self._offsets.data_ptr() + 8 * slot_of[e] * self._off_stride
         hd.c.max_graph_nodes = int(max(int(np.diff(host_ptrs[slot_of[t]]).max()) for t in store.node_types))
         hd.n_nodes = [0] * len(nat.node_types)
         hd.n_edges = [0] * len(nat.edge_types)

@@ -230,6 +230,12 @@ typedef struct hmp_batch {
   const int64_t* d_node_ptr[HMP_MAX_NODE_TYPES]; /* [n_graphs + 1] int64 row offsets of the node type, or NULL */
   int32_t n_graphs;
   int32_t max_graph_nodes;   /* largest per-graph node count over all types (host knowledge of the collation), 0 = unknown */
+  /* optional, with d_node_ptr of both endpoint types: [n_graphs + 1] int64 edge offsets of the edge type -- the caller vouches
+   * that the edges of graph g are entries [ptr[g], ptr[g+1]) of the edge list and join nodes of graph g only (what every
+   * collation of a list of graphs produces: [PyG] Batch.from_data_list, base_training_job.py:164-168).  The single-launch plan
+   * build then reads, per block of rows, only the edges of the graphs that own those rows instead of the whole list.  An edge
+   * found outside its graph's rows sets status bit 4.  NULL: no assumption about the edge order. */
+  const int64_t* d_edge_ptr[HMP_MAX_EDGE_TYPES];
 } hmp_batch;
 
 typedef struct hmp_train_args {

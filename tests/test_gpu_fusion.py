@@ -563,3 +563,60 @@ def test_ell_id_table_gathers_are_bit_identical(monkeypatch, kw_over, n_graphs, 
     assert res["1"][3] == res["0"][3]
     for k, p0 in res["0"][4].items():
         assert torch.equal(res["1"][4][k], p0), k
+
+
+@pytest.mark.parametrize("kw_over,n_graphs", [({}, 32), ({}, 1), ({"hidden_dim": 128, "num_layers": 4}, 9), ({}, 300)])
+def test_plan_from_graph_sorted_edge_lists_is_bit_identical(monkeypatch, kw_over, n_graphs):
+    """collate() records where each graph's edges start (the per-edge-type ptr): the single-launch plan build then reads, per
+    block of rows, only the edges of the graphs that own those rows (hmp_batch::d_edge_ptr).  HMP_PLAN_SLICED=0 reads the whole
+    list per block as before: same CSR / CSC arrays, so predictions, gradients and optimiser steps are bit-identical."""
+    kw = dict(SAGE_KW, **kw_over)
+    batch = workloads.config2_batch(n_graphs)
+    assert batch["objects", "objects_to_objects", "objects"].ptr.numel() == n_graphs + 1
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HMP_PLAN_SLICED", mode)
+        with fuse_env("1"):
+            _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+            res[mode] = run_fwd_bwd(net, batch, "rooms")
+            assert net.native().read_state()[1] == 0
+            step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, use_graph=False)
+            gb = batch.to(DEV)
+            for _ in range(3):
+                step(gb, gb["rooms"].y)
+            res[mode] += (step.loss(), {k: p.detach().clone() for k, p in net.named_parameters()})
+            assert net.native().read_state()[1] == 0
+    monkeypatch.delenv("HMP_PLAN_SLICED")
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g in res["0"][2].items():
+        if g is not None:
+            assert torch.equal(res["1"][2][k], g), k
+    assert res["1"][3] == res["0"][3]
+    for k, p0 in res["0"][4].items():
+        assert torch.equal(res["1"][4][k], p0), k
+
+
+def test_edge_offsets_that_do_not_match_the_edge_order_are_flagged():
+    """the caller vouches for graph-sorted edges; an edge list in another order under the same offsets sets status bit 4
+    (results are then unspecified); without the offsets any order is accepted"""
+    batch = workloads.config2_batch(6)
+    et = ("objects", "objects_to_objects", "objects")
+    perm = torch.randperm(batch[et].edge_index.size(1), generator=torch.Generator().manual_seed(1))
+    batch[et].edge_index = batch[et].edge_index[:, perm].contiguous()
+    with fuse_env("1"):
+        _, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+        net.eval()
+        net(batch.to(DEV))
+        assert net.native().read_state()[1] & 4
+        # the same edges without the vouching offsets: accepted, and equal to the sorted batch's result
+        ref_batch = workloads.config2_batch(6)
+        _, net2 = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+        net2.eval()
+        want = net2(ref_batch.to(DEV))
+        assert net2.native().read_state()[1] == 0
+        del batch[et].ptr
+        _, net3 = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+        net3.eval()
+        got = net3(batch.to(DEV))
+        assert net3.native().read_state()[1] == 0
+        torch.testing.assert_close(got, want, atol=1e-6, rtol=1e-6)

@@ -51,7 +51,8 @@ def main():
     show("agg_proj_fwd l1 (blk0)", a, [0, 1, 2])
     show("agg_row (last fwd launch)", a, [3, 4, 5, 6, 7])
     show("agg_bwd_dx l1 (blk0)", a, [8, 9, 10])
-    show("front gemm tile (blk0)", read(lib, "front"), [0, 1])
+    show("front gemm tile (blk0)", read(lib, "front"), [0, 2, 3, 5, 6, 7, 13, 14, 15, 4, 1])
+    show("front plan part 0 (job 0)", read(lib, "front"), [0, 8, 9, 10, 11, 12])
     show("gemm_tn_direct dW (blk0)", read(lib, "gemmd"), [8, 9])
     # the layer-0 projection alone: x[2831, 306] * Wp[192, 306]^T
     x = torch.randn(2831, 306, device=dev)
