@@ -625,11 +625,13 @@ __device__ __forceinline__ void agg_proj_tile(const AggArgs& a, const AggDst& D,
 template <int GS>
 __global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
   __shared__ float Hs[256 * 17];
+  KT_SPAN_BEGIN(40);
   int ti = 0;
   while (ti + 1 < a.n && (int)blockIdx.x >= a.bstart[ti + 1]) ++ti;
   karg_warm<9>((int)offsetof(AggArgs, d) + ti * (int)sizeof(AggDst), (int)sizeof(AggDst));
   const AggDst& D = a.d[ti];
   agg_proj_tile<GS>(a, D, ((int)blockIdx.x - D.block_start) * 16, D.n_rows, true, Hs);
+  KT_SPAN_END(40, ti);
 }
 
 // fixed-order sum of the per-row {loss, valid} pairs -> {loss_sum, count}; run by ONE block (256 threads)
@@ -1029,11 +1031,13 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
     finalize_loss(a.fin_row_lv, a.fin_rows, a.fin_out2, a.fin_state);
     return;
   }
+  KT_SPAN_BEGIN(48);
   int si = 0;
   while (si + 1 < a.n && (int)blockIdx.x >= a.bstart[si + 1]) ++si;
   karg_warm<10>((int)offsetof(TAggArgs, s) + si * (int)sizeof(TAggSrc), (int)sizeof(TAggSrc));
   const TAggSrc& S = a.s[si];
   agg_bwd_dx_tile<GS>(a, S, ((int)blockIdx.x - S.block_start) * 16, S.n_rows, true, Hs);
+  KT_SPAN_END(48, si);
 }
 
 // ----- graph-local chain: every launch between the front kernel and the weight-gradient GEMM, in ONE launch ------------------

@@ -76,10 +76,31 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
   static __device__ unsigned long long kt_buf[64];                                                       \
   extern "C" int hmp_debug_ktime_##tag(unsigned long long* out) {                                        \
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_buf), sizeof(kt_buf)) == hipSuccess ? 0 : 1;           \
+  }                                                                                                      \
+  extern "C" int hmp_debug_ktime_##tag##_set(const unsigned long long* in) {                             \
+    return hipMemcpyToSymbol(HIP_SYMBOL(kt_buf), in, sizeof(kt_buf)) == hipSuccess ? 0 : 1;              \
   }
 #define KT(i)                                                                      \
   do {                                                                             \
     if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = wall_clock64();           \
+  } while (0)
+// span of a launch over ALL its workgroups: slot i = earliest start, i + 1 = latest end, i + 2 + sub = longest workgroup of kind sub (thread 0 of
+// every workgroup; the host presets the slots: hmp_debug_ktime_<tag>_set)
+#define KT_SPAN_BEGIN(i)                                                  \
+  unsigned long long kt_span_t0 = 0;                                      \
+  do {                                                                    \
+    if (threadIdx.x == 0) {                                               \
+      kt_span_t0 = wall_clock64();                                        \
+      atomicMin(&kt_buf[i], kt_span_t0);                                  \
+    }                                                                     \
+  } while (0)
+#define KT_SPAN_END(i, sub)                                               \
+  do {                                                                    \
+    if (threadIdx.x == 0) {                                               \
+      const unsigned long long kt_now = wall_clock64();                   \
+      atomicMax(&kt_buf[(i) + 1], kt_now);                                \
+      atomicMax(&kt_buf[(i) + 2 + (sub)], kt_now - kt_span_t0);           \
+    }                                                                     \
   } while (0)
 // stamp once every vector load issued so far has landed
 #define KTW(i)                                   \
@@ -104,6 +125,12 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
   } while (0)
 #define KTW(i) \
   do {         \
+  } while (0)
+#define KT_SPAN_BEGIN(i) \
+  do {                   \
+  } while (0)
+#define KT_SPAN_END(i, sub) \
+  do {                      \
   } while (0)
 #define KT_NOW() 0ull
 #define KT_ADD(i, t0) \
