@@ -620,3 +620,58 @@ def test_edge_offsets_that_do_not_match_the_edge_order_are_flagged():
         got = net3(batch.to(DEV))
         assert net3.native().read_state()[1] == 0
         torch.testing.assert_close(got, want, atol=1e-6, rtol=1e-6)
+
+
+def _tiny_graph(rng, n_obj, n_room, feat=306):
+    """a scene graph of a handful of nodes; any of the four edge lists may be empty, n_room may be 0"""
+    from hydra_gnn_amd.data import HeteroData
+
+    g = HeteroData()
+    g["objects"].x = torch.from_numpy(rng.normal(0, 0.5, size=(n_obj, feat)).astype(np.float32))
+    g["rooms"].x = torch.from_numpy(rng.normal(0, 0.5, size=(n_room, 6)).astype(np.float32))
+    g["rooms"].y = torch.from_numpy(rng.integers(0, 26, size=n_room).astype(np.int64))
+
+    def edges(n_src, n_dst, n):
+        if n_src == 0 or n_dst == 0 or n == 0:
+            return torch.zeros(2, 0, dtype=torch.int64)
+        return torch.from_numpy(np.stack([rng.integers(0, n_src, size=n), rng.integers(0, n_dst, size=n)], 0).astype(np.int64))
+
+    g["objects", "objects_to_objects", "objects"].edge_index = edges(n_obj, n_obj, int(rng.integers(0, 3 * n_obj + 1)))
+    g["rooms", "rooms_to_rooms", "rooms"].edge_index = edges(n_room, n_room, int(rng.integers(0, 3)))
+    g["objects", "objects_to_rooms", "rooms"].edge_index = edges(n_obj, n_room, int(rng.integers(0, n_obj + 1)))
+    g["rooms", "rooms_to_objects", "objects"].edge_index = edges(n_room, n_obj, int(rng.integers(0, n_obj + 1)))
+    return g
+
+
+def test_plan_slices_with_many_tiny_graphs_and_empty_parts(monkeypatch):
+    """1 300 graphs of 1-6 objects and 0-2 rooms (more graphs than threads of a plan part; graphs without rooms, without edges of
+    a type; rows whose part boundary falls inside a graph): sliced and whole-list plan builds agree bit for bit, and with the oracle"""
+    from hydra_gnn_amd.data import collate
+
+    rng = np.random.Generator(np.random.PCG64(77))
+    graphs = [_tiny_graph(rng, int(rng.integers(1, 7)), int(rng.integers(0, 3))) for _ in range(1300)]
+    batch = collate(graphs)
+    assert batch["rooms"].x.size(0) > 0 and int(batch["objects"].ptr[-1]) == batch["objects"].x.size(0)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HMP_PLAN_SLICED", mode)
+        with fuse_env("1"):
+            ora, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
+            res[mode] = run_fwd_bwd(net, batch, "rooms")
+            assert net.native().read_state()[1] == 0
+    monkeypatch.delenv("HMP_PLAN_SLICED")
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g in res["0"][2].items():
+        if g is not None:
+            assert torch.equal(res["1"][2][k], g), k
+    o64 = copy.deepcopy(ora).double()
+    b64 = batch.to("cpu")
+    for t in b64.node_types:
+        b64[t].x = b64[t].x.double()
+    pred_ref = o64(b64)
+    y = batch["rooms"].y
+    o64.loss(pred_ref, y, y != 25).backward()
+    torch.testing.assert_close(res["1"][0].cpu().double(), pred_ref.detach(), atol=ATOL, rtol=RTOL)
+    for name, p in o64.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(res["1"][2][name].cpu().double(), p.grad, atol=ATOL, rtol=RTOL, msg=lambda m: f"{name}: {m}")
