@@ -421,6 +421,230 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight-stationary form of the NT product C[M, N] = A[M, K] * W[N, K]^T for tall problems (the projections of a 10^6-node
+// graph: M = 10^6, N = 768, K = 256) whose A is already stored as bf16 -- round 2.
+//
+// The tiled kernel above re-stages BOTH operands through LDS for every 256 x 256 output tile: 26 us per tile against an MFMA
+// floor of 3.4 us, with the matrix pipe 10-20 % busy and 29-64 % of the LDS cycles lost to bank conflicts
+// (profiles/r02_b_pmc_cfg5_mfma_lds.json).  Here a workgroup (4 waves, two workgroups per CU) owns 256 output columns for its whole life:
+//   * its slice of W (256 x K, rounded to bf16) lives in REGISTERS as ready-made MFMA operands -- 128 VGPRs per wave, loaded
+//     once, never staged again;
+//   * A streams through two 32 KB LDS buffers, 64 rows at a time, with global_load_lds_dwordx4: memory -> LDS directly, no
+//     VGPR staging, no ds_write.  The 16-byte chunks of a row are stored XOR-swizzled (position = chunk ^ (row & 31) -- each
+//     lane simply REQUESTS the chunk that belongs at its position), so the operand fetch of 32 rows x one chunk is a
+//     conflict-free ds_read_b128 without padding;
+//   * the product is computed transposed, D = W_tile * A_tile^T (both MFMA operands have the same per-lane layout, so that
+//     costs nothing): a lane then holds 4 CONSECUTIVE output columns of one output row per register quad -- 8-byte bf16
+//     stores instead of 2-byte ones.
+// The column slices of one row range sit on the same XCD (block ids 8 apart), so A comes out of HBM once.
+// Per 64-row tile and workgroup: 32 KB of A in, 32 KB of C out, 64 MFMAs per wave.  Two workgroups per CU drift apart in phase, so
+// one's MFMAs overlap the other's loads and stores (one 8-wave workgroup per CU ran its phases in lockstep: 656 us for the 10^6 x
+// 768 x 256 projection against the 288 us of its MFMA phase alone).
+constexpr int WS_ROWS = 64, WS_COLS = 256, WS_KMAX = 256, WS_THREADS = 256, WS_PER_CU = 2;
+struct WsArgs {
+  const uint16_t* A;  // bf16 [M][lda]
+  const float* W;     // fp32 [N][ldb]
+  void* C;            // bf16 or fp32 [M][ldc]
+  int M, N, K, lda, ldb, ldc, c_bf16;
+  int n_slices, groups, tiles_per_group, n_tiles;
+  int dbg;  // HMP_WS_DBG (measurements only): 1 = no stores, 2 = no loads after the first tile, 4 = no MFMAs
+};
+
+// KS: K / 16 fixed at compile time (16: the K = 256 of hidden-256 layers -- no branch between the k steps, so the operand reads of
+// step s + 1 are scheduled ahead of the MFMAs of step s), 0: any K <= 256 at run time
+template <int KS>
+__global__ __launch_bounds__(WS_THREADS, WS_PER_CU) void gemm_bf16_ws_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];  // [2][WS_ROWS][512 bytes]
+  const int b = blockIdx.x;
+  // blocks b, b + 8, b + 16 .. share an XCD: they take the column slices of the same row range
+  const int slice = (b >> 3) % a.n_slices;
+  const int group = (b & 7) + 8 * (b / (8 * a.n_slices));
+  const int n0 = slice * WS_COLS;
+  const int t_begin = group * a.tiles_per_group;
+  const int t_end = min(t_begin + a.tiles_per_group, a.n_tiles);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = 0, wn = w;  // 4 waves: all 64 rows of the tile x 64 columns each
+  const int K = KS ? KS * 16 : a.K, ksteps = K >> 4;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // ---- this wave's 64 columns of W as MFMA operands: wreg[j][s] = W[n0 + wn*64 + j*32 + l31][16 s + 8 half .. + 8]
+  bf16x8 wreg[2][WS_KMAX / 16];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + l31;
+    const float* wrow = a.W + (int64_t)min(col, a.N - 1) * a.ldb;
+#pragma unroll
+    for (int s = 0; s < WS_KMAX / 16; ++s) {
+      const int k = min(16 * s + 8 * half, K - 8);  // steps past K are never multiplied
+      const float4 lo = *reinterpret_cast<const float4*>(wrow + k);
+      const float4 hi = *reinterpret_cast<const float4*>(wrow + k + 4);
+      const bool live = col < a.N;
+      bf16x8 v;
+      v[0] = (__bf16)(live ? lo.x : 0.f); v[1] = (__bf16)(live ? lo.y : 0.f); v[2] = (__bf16)(live ? lo.z : 0.f); v[3] = (__bf16)(live ? lo.w : 0.f);
+      v[4] = (__bf16)(live ? hi.x : 0.f); v[5] = (__bf16)(live ? hi.y : 0.f); v[6] = (__bf16)(live ? hi.z : 0.f); v[7] = (__bf16)(live ? hi.w : 0.f);
+      wreg[j][s] = v;
+    }
+  }
+  if (t_begin >= t_end) return;  // block-uniform
+
+  // ---- A tile -> LDS: wave w requests rows 16 w .. 16 w + 15 of the tile, two rows (32 chunks each) per instruction
+  const int kchunks = K >> 3;  // 16-byte chunks per row that exist
+  auto request = [&](int t, int buf) {
+    const int m0 = t * WS_ROWS;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = (w * 8 + i) * 2 + half;          // row inside the tile (wave w: rows 16 w .. 16 w + 15)
+      const int c = l31 ^ (r & 31);                   // the chunk that belongs at position l31 of this row
+      const int64_t grow = min(m0 + r, a.M - 1);      // rows past M: a valid address, the products are never stored
+      const uint16_t* src = a.A + grow * a.lda + 8 * min(c, kchunks - 1);
+      unsigned char* dst = ws_lds + buf * (WS_ROWS * 512) + (w * 8 + i) * 1024;  // wave-uniform; lane l lands at + 16 l
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  // Order per tile: request t + 1 | MFMAs of t | wait (requests of t + 1, stores of t - 1: both a whole MFMA phase old) | barrier |
+  // stores of t.  The wait is for EVERYTHING outstanding (on gfx9 loads and stores share one counter and stores may complete out of
+  // order with loads, so a count that skips the newest stores would not prove the loads landed) -- placed where everything
+  // outstanding is old.
+  request(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    if (t + 1 < t_end && !(a.dbg & 2)) request(t + 1, buf ^ 1);  // the other buffer: every wave left its MFMAs of t - 1 before the last barrier
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    const unsigned char* Ab = ws_lds + buf * (WS_ROWS * 512);
+    auto kstep = [&](int s) {
+      bf16x8 av[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + l31;
+        av[i] = *reinterpret_cast<const bf16x8*>(Ab + row * 512 + (((2 * s + half) ^ l31) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[j][s], av[i], acc[j][i], 0, 0, 0);
+    };
+    if (!(a.dbg & 4)) {
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kstep(s);
+      } else {
+#pragma unroll
+        for (int s = 0; s < WS_KMAX / 16; ++s)
+          if (s < ksteps) kstep(s);  // block-uniform
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- D[j][i]: lane = output row m0 + wm*64 + i*32 + l31; registers 4 g .. 4 g + 3 = output columns n0 + wn*64 + j*32 + 4 half + 8 g ..
+    const int m0 = t * WS_ROWS;
+    if (a.c_bf16 && !(a.dbg & 1)) {  // block-uniform
+      // bf16 output: a lane's 8-byte pieces (4 columns of one row) written straight to memory touch 32 rows per instruction, 16
+      // bytes each -- measured 3.2 TB/s for the 1.5 GB of a config-5 projection, the kernel's bound.  The wave turns its 64 x 64
+      // block into row-major order through LDS instead and writes whole 128-byte lines, 8 rows per instruction.  Its staging
+      // area is the 8 KB of the consumed A buffer that only this wave's next requests overwrite (rows 16 w .. of the tile), so
+      // wave-local ordering is all the synchronisation this needs.  8-byte units are XOR-swizzled by the row.
+      unsigned char* stg = ws_lds + buf * (WS_ROWS * 512) + w * 8192;  // [64 rows][128 bytes]
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int u = j * 8 + half + 2 * g;  // 8-byte unit of the row: columns 4 u .. 4 u + 3
+            bf16x4 o;
+            o[0] = (__bf16)acc[j][i][4 * g + 0]; o[1] = (__bf16)acc[j][i][4 * g + 1];
+            o[2] = (__bf16)acc[j][i][4 * g + 2]; o[3] = (__bf16)acc[j][i][4 * g + 3];
+            *reinterpret_cast<bf16x4*>(stg + r * 128 + ((u ^ (r & 15)) << 3)) = o;
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own writes
+      const int q = lane & 7;  // 16-byte piece of the row: columns 8 q .. 8 q + 7
+#pragma unroll 2
+      for (int k = 0; k < 8; ++k) {
+        const int r = k * 8 + (lane >> 3);
+        const uint2 lo = *reinterpret_cast<const uint2*>(stg + r * 128 + (((2 * q) ^ (r & 15)) << 3));
+        const uint2 hi = *reinterpret_cast<const uint2*>(stg + r * 128 + (((2 * q + 1) ^ (r & 15)) << 3));
+        const int row = m0 + wm * 64 + r;
+        const int col = n0 + wn * 64 + 8 * q;
+        __bf16* dst = reinterpret_cast<__bf16*>(a.C) + (int64_t)row * a.ldc + col;
+        if (row < a.M && col + 8 <= a.N) {
+          *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else if (row < a.M && col < a.N) {  // N is a multiple of 4: the first half of the piece exists
+          *reinterpret_cast<uint2*>(dst) = lo;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged reads done before this wave's next requests reuse the area
+    } else if (!(a.dbg & 1)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + wm * 64 + i * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wn * 64 + j * 32 + 4 * half + 8 * g;
+          if (row < a.M && col < a.N)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)row * a.ldc + col) =
+                make_float4(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+        }
+    }
+    }
+  }
+}
+
+// problems of a launch the weight-stationary kernel takes (one launch each); false: the tiled kernel
+static bool ws_takes(const GemmProblem& p, bool want_split) {
+  const char* v = getenv("HMP_GEMM_WS");  // 0: the tiled kernel for every problem (tests compare the two)
+  const bool on = !(v && v[0] == '0');
+  return on && !want_split && !p.trans_a && p.trans_b && p.a_bf16 && p.a_split == 0 && !p.b_bf16 && p.epi == EPI_NONE && !p.aug_ones &&
+         p.K >= 16 && p.K <= WS_KMAX && (p.K & 15) == 0 && (p.lda & 7) == 0 && (p.ldb & 3) == 0 && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && p.M >= 32768 && p.N >= 64;
+}
+static int ws_launch(const GemmProblem& p, hipStream_t st) {
+  WsArgs a;
+  a.A = reinterpret_cast<const uint16_t*>(p.A); a.W = p.B; a.C = p.C;
+  a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc; a.c_bf16 = p.c_bf16;
+  a.n_slices = cdiv(p.N, WS_COLS);
+  a.n_tiles = cdiv(p.M, WS_ROWS);
+  {
+    const char* dv = getenv("HMP_WS_DBG");
+    a.dbg = dv ? atoi(dv) : 0;
+  }
+  int n_cu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  }
+  // groups in sets of 8 (one per XCD); as many sets as fit the chip, at least one
+  int sets = WS_PER_CU * n_cu / (8 * a.n_slices);
+  if (sets < 1) sets = 1;
+  a.groups = 8 * sets;
+  if (a.groups > a.n_tiles) a.groups = ((a.n_tiles + 7) / 8) * 8;
+  a.tiles_per_group = cdiv(a.n_tiles, a.groups);
+  static const int rc = [] {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ws_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_ROWS * 512) != hipSuccess) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_ROWS * 512) != hipSuccess) return 1;
+    return 0;
+  }();
+  HMP_CHECK_ARG(rc == 0, "gemm_bf16: could not raise the dynamic LDS limit of the weight-stationary kernel");
+  if (p.K == 256) hipLaunchKernelGGL(gemm_bf16_ws_kernel<16>, dim3(a.groups * a.n_slices), dim3(WS_THREADS), 2 * WS_ROWS * 512, st, a);
+  else hipLaunchKernelGGL(gemm_bf16_ws_kernel<0>, dim3(a.groups * a.n_slices), dim3(WS_THREADS), 2 * WS_ROWS * 512, st, a);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
 // Weight gradients (TN, split-K over node chunks) of a large batch also take the 256x256 tile: the 128x128 tile re-reads dZ
 // once per 128 input columns and H once per 128 packed rows (12 GB of operand traffic for the 768 x 257 x 10^6 problem of
 // config 5, 6.5 ms); the big tile halves that, provided the launch still fills the chip: 1 block per CU, so the split aims at
@@ -437,6 +661,24 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
 // form (the 256 x 256 bf16 weight tile fits LDS).
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
+  {  // tall NT products over a bf16 A: the weight-stationary kernel, one launch per problem; the rest stays with the tiled kernel
+    GemmBatch rest;
+    memset(&rest, 0, sizeof(rest));
+    int taken = 0;
+    for (int i = 0; i < gb.n; ++i) {
+      if (ws_takes(gb.p[i], want_split)) {
+        HMP_TRY(ws_launch(gb.p[i], st));
+        ++taken;
+      } else {
+        rest.p[rest.n++] = gb.p[i];
+      }
+    }
+    if (taken) {
+      for (int i = 0; i < gb.n; ++i) gb.p[i].ksplit = 1;  // (no split-K in this branch: want_split is false)
+      if (rest.n == 0) return HMP_OK;
+      return gemm_bf16_launch(rest, want_split, max_slabs, st);  // (no problem of `rest` is taken again)
+    }
+  }
   // 256x256 tiles when every problem is a product with at least 4096 x 192 outputs (plain) / 192 x 192 outputs over >= 2^17
   // nodes in one problem (split-K weight gradients; narrow companions such as the 28-row last layer ride along on one tile)
   bool big = true, tn_wide = false;
@@ -532,6 +774,27 @@ extern "C" int hmp_gemm_bf16(const float* d_a, int32_t lda, int32_t trans_a, con
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.trans_a = trans_a; p.trans_b = trans_b;
+  p.n_real = N;
+  p.epi = EPI_NONE;
+  if (M == 0 || N == 0) return HMP_OK;
+  return gemm_bf16_launch(gb, false, 1, (hipStream_t)stream);
+}
+
+extern "C" int hmp_gemm_bf16_a16(const uint16_t* d_a, int32_t lda, const float* d_w, int32_t ldw, void* d_c, int32_t ldc, int32_t c_bf16,
+                                 int32_t M, int32_t N, int32_t K, void* stream) {
+  using namespace hmp;
+  HMP_CHECK_ARG(d_a && d_w && d_c, "hmp_gemm_bf16_a16: null pointer");
+  HMP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && lda >= K && ldw >= K && ldc >= N, "hmp_gemm_bf16_a16: bad shape");
+  HMP_CHECK_ARG((lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d_a) & 7) == 0, "hmp_gemm_bf16_a16: rows of A must be 8-byte aligned");
+  GemmBatch gb;
+  memset(&gb, 0, sizeof(gb));
+  gb.n = 1;
+  GemmProblem& p = gb.p[0];
+  p.A = reinterpret_cast<const float*>(d_a); p.B = d_w; p.C = reinterpret_cast<float*>(d_c);
+  p.a_bf16 = 1; p.c_bf16 = c_bf16 ? 1 : 0;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldw; p.ldc = ldc;
+  p.trans_a = 0; p.trans_b = 1;
   p.n_real = N;
   p.epi = EPI_NONE;
   if (M == 0 || N == 0) return HMP_OK;

@@ -115,6 +115,7 @@ SIGNATURES = {
     "hmp_segment_mean_bwd": (C.c_int, [_VP, _I32, _I32, Plan, _VP, _I32, _VP]),
     "hmp_gemm_f32": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     "hmp_gemm_bf16": (C.c_int, [_VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "hmp_gemm_bf16_a16": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "hmp_net_set_compute": (C.c_int, [_VP, _I32]),
     "hmp_collate_rows": (C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, _I32, C.c_int64, _VP, _VP]),
     "hmp_collate_edges": (C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, _I32, C.c_int64, _VP, _VP]),

@@ -92,6 +92,12 @@ int hmp_segment_mean_bwd(const float* d_gout, int32_t ldg, int32_t F, hmp_plan p
 /* same problem on the bf16 matrix pipe (operands rounded to bf16, fp32 accumulate); unit-test entry of gemm_bf16.hip */
 int hmp_gemm_bf16(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b, float* d_c,
                   int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* C[M, N] = A[M, K] * W[N, K]^T with A STORED as bf16 (the hidden activations of bf16 compute mode, lda in elements, rows 8-byte
+ * aligned), W fp32 (rounded to bf16 on the way in), fp32 accumulation, C written as bf16 (c_bf16 != 0, ldc in elements) or fp32.
+ * Tall problems (M >= 32768, K <= 256, 16-byte aligned rows) run on the weight-stationary kernel (csrc/gemm_bf16.hip); this is
+ * the projection of the reference's SAGEConv.lin_l / lin_r at 10^6 nodes ([PyG] sage_conv.py: `self.lin_l(out)`). */
+int hmp_gemm_bf16_a16(const uint16_t* d_a, int32_t lda, const float* d_w, int32_t ldw, void* d_c, int32_t ldc, int32_t c_bf16,
+                      int32_t M, int32_t N, int32_t K, void* stream);
 int hmp_gemm_f32(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b,
                  float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 

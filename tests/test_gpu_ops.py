@@ -327,3 +327,33 @@ def test_gemm_128x128_register_tiling_is_bit_identical_to_64x64(ta, tb, monkeypa
     assert torch.equal(big, small)
     ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
     torch.testing.assert_close(big.double(), ref, atol=2e-4, rtol=1e-5)  # |sum of 306 products of N(0,1)| ~ 17: 1e-5 relative
+
+
+@pytest.mark.parametrize("M,N,K,c16,pad", [(40000, 768, 256, True, 0), (40003, 700, 256, True, 8), (33000, 256, 128, True, 0),
+                                            (36000, 768, 64, False, 8), (32768, 64, 16, True, 0), (50001, 516, 256, False, 0)])
+def test_bf16_activation_projection_weight_stationary_kernel(monkeypatch, M, N, K, c16, pad):
+    """hmp_gemm_bf16_a16 (C = A * W^T, A stored as bf16): tall problems run on the weight-stationary kernel (W slice in registers, A
+    through swizzled LDS by direct loads, transposed product, coalesced bf16 stores); HMP_GEMM_WS=0 sends the same call to the
+    tiled kernel.  Both against float64 on the rounded operands; ragged M / N, padded leading dimensions, every K class."""
+    lib = _lib.require_device()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(M, K + pad, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    W = torch.randn(N, K + pad, device="cuda", generator=g) * 0.1
+    ref = A[:, :K].double() @ W[:, :K].to(torch.bfloat16).double().t()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HMP_GEMM_WS", mode)
+        Cc = torch.full((M, N + pad), 7.0, device="cuda", dtype=torch.bfloat16 if c16 else torch.float32)
+        _lib.check(lib.hmp_gemm_bf16_a16(A.data_ptr(), K + pad, W.data_ptr(), K + pad, Cc.data_ptr(), N + pad, 1 if c16 else 0, M, N, K,
+                                         _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        got = Cc[:, :N].double()
+        tol = 8e-3 if c16 else 2e-5  # bf16 output: half an ulp of 2^-8 relative; fp32: accumulation order only
+        err = ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+        assert err < tol, (mode, err)
+        if pad:
+            assert torch.all(Cc[:, N:] == 7.0)  # nothing written past the N columns
+        outs[mode] = Cc[:, :N].clone()
+    monkeypatch.delenv("HMP_GEMM_WS")
+    # same products in the same k order on the same matrix pipe: the two kernels agree to the last bit
+    assert torch.equal(outs["1"], outs["0"])
