@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
 // 768 x 256 projection against the 288 us of its MFMA phase alone).
 constexpr int WS_ROWS = 64, WS_COLS = 256, WS_KMAX = 256, WS_THREADS = 256, WS_PER_CU = 2;
 struct WsArgs {
-  const uint16_t* A;  // bf16 [M][lda]
+  const void* A;      // bf16 or fp32 [M][lda] (lda in elements)
   const float* W;     // fp32 [N][ldb]
   void* C;            // bf16 or fp32 [M][ldc]
   int M, N, K, lda, ldb, ldc, c_bf16;
@@ -453,7 +453,10 @@ struct WsArgs {
 
 // KS: K / 16 fixed at compile time (16: the K = 256 of hidden-256 layers -- no branch between the k steps, so the operand reads of
 // step s + 1 are scheduled ahead of the MFMAs of step s), 0: any K <= 256 at run time
-template <int KS>
+// AF32: A is stored as fp32 (the input features of layer 0, or every layer when the activations stay fp32).  Its rows go through
+// the same 512-byte LDS rows in PARTS of 128 floats (a K = 256 tile is two pipeline units sharing one accumulator set); an
+// operand is two 16-byte reads rounded to bf16 on the way into the MFMA -- what the tiled kernel does on the way into LDS.
+template <int KS, bool AF32>
 __global__ __launch_bounds__(WS_THREADS, WS_PER_CU) void gemm_bf16_ws_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];  // [2][WS_ROWS][512 bytes]
   const int b = blockIdx.x;
@@ -489,57 +492,93 @@ __global__ __launch_bounds__(WS_THREADS, WS_PER_CU) void gemm_bf16_ws_kernel(con
   if (t_begin >= t_end) return;  // block-uniform
 
   // ---- A tile -> LDS: wave w requests rows 16 w .. 16 w + 15 of the tile, two rows (32 chunks each) per instruction
-  const int kchunks = K >> 3;  // 16-byte chunks per row that exist
-  auto request = [&](int t, int buf) {
+  constexpr int ESZ = AF32 ? 4 : 2;                  // bytes per element of A
+  constexpr int CE = 16 / ESZ;                       // elements per 16-byte chunk
+  constexpr int PMAX = AF32 ? 2 : 1;                 // pipeline units (parts of 32 chunks) per tile
+  const int P = AF32 ? (KS ? KS / 8 : (K + 127) >> 7) : 1;
+  const int kchunks = K / CE;                        // 16-byte chunks per row that exist
+  const unsigned char* Abytes = reinterpret_cast<const unsigned char*>(a.A);
+  auto request = [&](int t, int h, int buf) {
     const int m0 = t * WS_ROWS;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = (w * 8 + i) * 2 + half;          // row inside the tile (wave w: rows 16 w .. 16 w + 15)
-      const int c = l31 ^ (r & 31);                   // the chunk that belongs at position l31 of this row
+      const int c = 32 * h + (l31 ^ (r & 31));        // the chunk that belongs at position l31 of this row
       const int64_t grow = min(m0 + r, a.M - 1);      // rows past M: a valid address, the products are never stored
-      const uint16_t* src = a.A + grow * a.lda + 8 * min(c, kchunks - 1);
+      const unsigned char* src = Abytes + (grow * a.lda + (int64_t)CE * min(c, kchunks - 1)) * ESZ;
       unsigned char* dst = ws_lds + buf * (WS_ROWS * 512) + (w * 8 + i) * 1024;  // wave-uniform; lane l lands at + 16 l
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
-  // Order per tile: request t + 1 | MFMAs of t | wait (requests of t + 1, stores of t - 1: both a whole MFMA phase old) | barrier |
-  // stores of t.  The wait is for EVERYTHING outstanding (on gfx9 loads and stores share one counter and stores may complete out of
-  // order with loads, so a count that skips the newest stores would not prove the loads landed) -- placed where everything
-  // outstanding is old.
-  request(t_begin, 0);
+  // Order per unit: request the next unit | MFMAs of this one | wait (the next unit's requests, the previous tile's stores: both a
+  // whole MFMA phase old) | barrier | stores (last part of a tile).  The wait is for EVERYTHING outstanding (on gfx9 loads and
+  // stores share one counter and stores may complete out of order with loads, so a count that skips the newest stores would not
+  // prove the loads landed) -- placed where everything outstanding is old.
+  request(t_begin, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  f32x16 acc[2][2];
   for (int t = t_begin; t < t_end; ++t) {
-    const int buf = (t - t_begin) & 1;
-    if (t + 1 < t_end && !(a.dbg & 2)) request(t + 1, buf ^ 1);  // the other buffer: every wave left its MFMAs of t - 1 before the last barrier
-    f32x16 acc[2][2];
+    int buf = 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-    const unsigned char* Ab = ws_lds + buf * (WS_ROWS * 512);
-    auto kstep = [&](int s) {
-      bf16x8 av[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + l31;
-        av[i] = *reinterpret_cast<const bf16x8*>(Ab + row * 512 + (((2 * s + half) ^ l31) << 4));
+    for (int h = 0; h < PMAX; ++h) {
+      if (h >= P) break;  // block-uniform
+      buf = ((t - t_begin) * P + h) & 1;
+      // the other buffer: every wave left its MFMAs of the previous unit before the last barrier
+      if (!(a.dbg & 2)) {
+        if (h + 1 < P) request(t, h + 1, buf ^ 1);
+        else if (t + 1 < t_end) request(t + 1, 0, buf ^ 1);
       }
+      if (h == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[j][s], av[i], acc[j][i], 0, 0, 0);
-    };
-    if (!(a.dbg & 4)) {
-      if constexpr (KS > 0) {
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) kstep(s);
-      } else {
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+      }
+      const unsigned char* Ab = ws_lds + buf * (WS_ROWS * 512);
+      auto kstep = [&](int s) {  // s: k step of the tile (compile-time); the part holds steps 8 h .. 8 h + 7 when AF32
+        if constexpr (AF32) {
+          const int sp = s - 8 * h;
 #pragma unroll
-        for (int s = 0; s < WS_KMAX / 16; ++s)
-          if (s < ksteps) kstep(s);  // block-uniform
+          for (int i = 0; i < 2; ++i) {  // one row tile at a time: 8 floats + their bf16 image are all the registers this needs
+            const int row = i * 32 + l31;
+            const float4 f0 = *reinterpret_cast<const float4*>(Ab + row * 512 + (((4 * sp + 2 * half) ^ l31) << 4));
+            const float4 f1 = *reinterpret_cast<const float4*>(Ab + row * 512 + (((4 * sp + 2 * half + 1) ^ l31) << 4));
+            bf16x8 av;
+            av[0] = (__bf16)f0.x; av[1] = (__bf16)f0.y; av[2] = (__bf16)f0.z; av[3] = (__bf16)f0.w;
+            av[4] = (__bf16)f1.x; av[5] = (__bf16)f1.y; av[6] = (__bf16)f1.z; av[7] = (__bf16)f1.w;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[j][s], av, acc[j][i], 0, 0, 0);
+          }
+        } else {
+          bf16x8 av[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            av[i] = *reinterpret_cast<const bf16x8*>(Ab + row * 512 + (((2 * s + half) ^ l31) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[j][s], av[i], acc[j][i], 0, 0, 0);
+        }
+      };
+      if (!(a.dbg & 4)) {
+        constexpr int SPP = AF32 ? 8 : WS_KMAX / 16;  // k steps per part
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int s = h * SPP; s < (h + 1) * SPP && s < KS; ++s) kstep(s);
+        } else {
+#pragma unroll
+          for (int s = h * SPP; s < (h + 1) * SPP; ++s)
+            if (s < ksteps) kstep(s);  // block-uniform
+        }
+      }
+      if (h + 1 < P) {  // more parts of this tile: hand the buffers over and go on accumulating
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -606,14 +645,16 @@ __global__ __launch_bounds__(WS_THREADS, WS_PER_CU) void gemm_bf16_ws_kernel(con
 static bool ws_takes(const GemmProblem& p, bool want_split) {
   const char* v = getenv("HMP_GEMM_WS");  // 0: the tiled kernel for every problem (tests compare the two)
   const bool on = !(v && v[0] == '0');
-  return on && !want_split && !p.trans_a && p.trans_b && p.a_bf16 && p.a_split == 0 && !p.b_bf16 && p.epi == EPI_NONE && !p.aug_ones &&
-         p.K >= 16 && p.K <= WS_KMAX && (p.K & 15) == 0 && (p.lda & 7) == 0 && (p.ldb & 3) == 0 && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+  // an fp32 A only at K = 256 (the run-time-K form of that variant does not fit the register file: 75 spilled registers)
+  if (!p.a_bf16 && p.K != 256) return false;
+  return on && !want_split && !p.trans_a && p.trans_b && p.a_split == 0 && !p.b_bf16 && p.epi == EPI_NONE && !p.aug_ones &&
+         p.K >= 16 && p.K <= WS_KMAX && (p.K & 15) == 0 && (p.lda & (p.a_bf16 ? 7 : 3)) == 0 && (p.ldb & 3) == 0 && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && p.M >= 32768 && p.N >= 64;
 }
 static int ws_launch(const GemmProblem& p, hipStream_t st) {
   WsArgs a;
-  a.A = reinterpret_cast<const uint16_t*>(p.A); a.W = p.B; a.C = p.C;
+  a.A = p.A; a.W = p.B; a.C = p.C;
   a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc; a.c_bf16 = p.c_bf16;
   a.n_slices = cdiv(p.N, WS_COLS);
   a.n_tiles = cdiv(p.M, WS_ROWS);
@@ -633,14 +674,14 @@ static int ws_launch(const GemmProblem& p, hipStream_t st) {
   a.groups = 8 * sets;
   if (a.groups > a.n_tiles) a.groups = ((a.n_tiles + 7) / 8) * 8;
   a.tiles_per_group = cdiv(a.n_tiles, a.groups);
-  static const int rc = [] {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ws_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_ROWS * 512) != hipSuccess) return 1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_ROWS * 512) != hipSuccess) return 1;
-    return 0;
-  }();
-  HMP_CHECK_ARG(rc == 0, "gemm_bf16: could not raise the dynamic LDS limit of the weight-stationary kernel");
-  if (p.K == 256) hipLaunchKernelGGL(gemm_bf16_ws_kernel<16>, dim3(a.groups * a.n_slices), dim3(WS_THREADS), 2 * WS_ROWS * 512, st, a);
-  else hipLaunchKernelGGL(gemm_bf16_ws_kernel<0>, dim3(a.groups * a.n_slices), dim3(WS_THREADS), 2 * WS_ROWS * 512, st, a);
+  const dim3 grid(a.groups * a.n_slices), block(WS_THREADS);
+  const size_t lds = 2 * WS_ROWS * 512;  // 64 KB: the default dynamic limit
+  if (p.a_bf16) {
+    if (p.K == 256) hipLaunchKernelGGL((gemm_bf16_ws_kernel<16, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_ws_kernel<0, false>), grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_ws_kernel<16, true>), grid, block, lds, st, a);  // (ws_takes: K == 256 only for an fp32 A)
+  }
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

@@ -357,3 +357,26 @@ def test_bf16_activation_projection_weight_stationary_kernel(monkeypatch, M, N, 
     monkeypatch.delenv("HMP_GEMM_WS")
     # same products in the same k order on the same matrix pipe: the two kernels agree to the last bit
     assert torch.equal(outs["1"], outs["0"])
+
+
+@pytest.mark.parametrize("M,N", [(40000, 768), (33001, 260)])
+def test_fp32_activation_projection_weight_stationary_kernel(monkeypatch, M, N):
+    """hmp_gemm_bf16 (fp32 A rounded to bf16 on the way into the MFMA) at K = 256, tall: the fp32-A form of the weight-stationary
+    kernel (rows through LDS in two parts of 128 floats) against the tiled kernel (bit for bit) and float64 on the rounded operands"""
+    lib = _lib.require_device()
+    K = 256
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = torch.randn(M, K, device="cuda", generator=g) * 0.5
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.1
+    ref = A.to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().t()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HMP_GEMM_WS", mode)
+        Cc = torch.empty(M, N, device="cuda")
+        _lib.check(lib.hmp_gemm_bf16(A.data_ptr(), K, 0, W.data_ptr(), K, 1, Cc.data_ptr(), N, M, N, K, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        err = ((Cc.double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+        assert err < 2e-5, (mode, err)
+        outs[mode] = Cc
+    monkeypatch.delenv("HMP_GEMM_WS")
+    assert torch.equal(outs["1"], outs["0"])

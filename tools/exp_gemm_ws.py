@@ -34,6 +34,27 @@ def run(M, N, K, c16, reps=20, check=True):
         assert err < tol * max(ref.abs().max().item(), 1.0), err
         msg += f"  max err {err:.2e}"
     print(msg, flush=True)
+def run32(M, N, K, reps=10):
+    torch.manual_seed(0)
+    A = torch.randn(M, K, device=dev) * 0.5
+    W = torch.randn(N, K, device=dev) * 0.1
+    Cc = torch.empty(M, N, device=dev)
+    st = _lib.stream_ptr()
+    call = lambda: _lib.check(lib.hmp_gemm_bf16(A.data_ptr(), K, 0, W.data_ptr(), K, 1, Cc.data_ptr(), N, M, N, K, st))
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    rows = torch.arange(M - 4096, M, device=dev)
+    ref = A[rows].to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().t()
+    err = (Cc[rows].double() - ref).abs().max().item()
+    print(f"fp32 A: M={M:8d} N={N:4d} K={K:4d} C=fp32: {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  max err {err:.2e}", flush=True)
+run32(1_000_000, 768, 256)
 run(1_000_000, 768, 256, True)
 run(1_000_000, 768, 256, False, reps=10)
 run(1_000_000, 256, 256, True)
