@@ -244,6 +244,40 @@ __global__ __launch_bounds__(256) void plan_rank_kernel(const PlanBatch pb) {
           J.t_col[pos] = other;  // destination endpoint
         }
       }
+    } else if (__all(deg <= 32)) {
+      // rows of 17..32 entries (the out-degrees of a 10^6-object graph scatter around its mean of 16: nearly every wavefront holds
+      // one): two entries per lane, still ranked through shuffles -- the loop below re-reads the row once per entry
+      const int m0 = lane < deg ? tmp[b + lane] : 0x7fffffff, m1 = lane + 16 < deg ? tmp[b + lane + 16] : 0x7fffffff;
+      const int o0 = lane < deg ? tmpc[b + lane] : 0, o1 = lane + 16 < deg ? tmpc[b + lane + 16] : 0;
+      int r0 = 0, r1 = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int v0 = __shfl(m0, i, 16), v1 = __shfl(m1, i, 16);
+        r0 += ((v0 < m0) ? 1 : 0) + ((v1 < m0) ? 1 : 0);
+        r1 += ((v0 < m1) ? 1 : 0) + ((v1 < m1) ? 1 : 0);
+      }
+      if (lane < deg) {
+        const int pos = b + r0;
+        if (dir == 0) {
+          J.eid[pos] = m0;
+          J.col[pos] = o0;
+          if (pb.need_tpos) J.pos_of_eid[m0] = pos;
+        } else {
+          J.t_eid[pos] = m0;
+          J.t_col[pos] = o0;
+        }
+      }
+      if (lane + 16 < deg) {
+        const int pos = b + r1;
+        if (dir == 0) {
+          J.eid[pos] = m1;
+          J.col[pos] = o1;
+          if (pb.need_tpos) J.pos_of_eid[m1] = pos;
+        } else {
+          J.t_eid[pos] = m1;
+          J.t_col[pos] = o1;
+        }
+      }
     } else {
       for (int c = lane; c < deg; c += 16) {
         const int mine = tmp[b + c];
