@@ -623,7 +623,7 @@ __device__ __forceinline__ void agg_proj_tile(const AggArgs& a, const AggDst& D,
 }
 
 template <int GS>
-__global__ __launch_bounds__(256, GS >= 32 ? 4 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
+__global__ __launch_bounds__(256, GS >= 32 ? 2 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
   __shared__ float Hs[256 * 17];
   KT_SPAN_BEGIN(40);
   int ti = 0;
