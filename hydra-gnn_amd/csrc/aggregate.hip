@@ -1237,6 +1237,7 @@ struct WinFwd {
   AggDst d;  // ONE destination entry, win_in >= 0
   int mean;
   int n_chunks, chunks_per_block;
+  int dbg;   // HMP_WIN_DBG=1 (measurement only, wrong results): no edge reads global memory
 };
 struct WinBwd {
   TAggSrc s;  // ONE source entry, win_out >= 0
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
             const bool inw = lane < cnt && wq && idv >= wlo && idv < whi;
             const int lov = inw ? (idv & (WRING - 1)) * WIN_ROW_BYTES : WRING * WIN_ROW_BYTES;
             const int gov = (lane < cnt && !inw) ? idv * (ldq * 2) : 0;
-            const unsigned long long mnull = __ballot(inw || lane >= cnt);  // edges that read nothing from global memory
+            const unsigned long long mnull = __ballot(inw || lane >= cnt) | (a.dbg ? ~0ull : 0ull);  // edges that read nothing from global memory (dbg: measurement only)
             auto batch = [&](int u0, auto nb) {
               constexpr int NB = decltype(nb)::value;
               uint2 va[NB];
@@ -1830,6 +1831,10 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
         w.d.win_in = wi;
         w.mean = a.mean;
         w.n_chunks = cdiv(w.d.n_rows, WR);
+        {
+          const char* dv = getenv("HMP_WIN_DBG");
+          w.dbg = dv ? atoi(dv) : 0;
+        }
         const int grid = agg_win_grid(w.n_chunks, w.chunks_per_block);
         if (a.hb16) hipLaunchKernelGGL((agg_fwd_win_kernel<true>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);
         else hipLaunchKernelGGL((agg_fwd_win_kernel<false>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);
