@@ -1480,6 +1480,20 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
             auto batch = [&](int u0, auto nb) {
               constexpr int NB = decltype(nb)::value;
               uint2 va[NB];
+              // A batch none of whose edges leaves the window (43 % of them at 10 % far neighbours) issues LDS reads only: even a
+              // buffer read through the zero-record descriptor travels the vector-memory pipeline, and the batch waited ~1 us for
+              // its eight of them (measured: 4.2 us per row, ~3 batches; nulling every far read left 89 % of the kernel's time).
+              if (((~mnull >> u0) & ((1ull << NB) - 1ull)) == 0ull) {  // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NB; ++t) va[t] = *reinterpret_cast<const uint2*>(ring + __builtin_amdgcn_readlane(lov, u0 + t) + lane * 8);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                  Acc<4> w;
+                  widen_bf16x4(w, va[t]);
+                  acc.add(w);
+                }
+                return;
+              }
               u32x2 vb[NB];
 #pragma unroll
               for (int t = 0; t < NB; ++t) {
@@ -1646,6 +1660,17 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_bwd_win_kernel(const WinBwd a
           auto batch = [&](int u0, auto nb) {
             constexpr int NB = decltype(nb)::value;
             uint2 va[NB];
+            if (((~mnull >> u0) & ((1ull << NB) - 1ull)) == 0ull) {  // wave-uniform: no edge of the batch leaves the window (see agg_fwd_win_kernel)
+#pragma unroll
+              for (int t = 0; t < NB; ++t) va[t] = *reinterpret_cast<const uint2*>(ring + __builtin_amdgcn_readlane(lov, u0 + t) + lane * 8);
+#pragma unroll
+              for (int t = 0; t < NB; ++t) {
+                Acc<4> w;
+                widen_bf16x4(w, va[t]);
+                if (a.mean) acc.add_mul(w, __int_as_float(__builtin_amdgcn_readlane(dvi, u0 + t))); else acc.add(w);
+              }
+              return;
+            }
             u32x2 vb[NB];
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
