@@ -428,8 +428,205 @@ static int launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t
   return HMP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradients of a LARGE batch of narrow layers: C[M, N] = A[K, M]^T * [B | 1][K, N] with K = 10^5 .. 10^6 nodes, M <= 192
+// stacked output columns, N = input width + 1 (the reference's own batch size: 2048 MP3D graphs = 176 k objects, M = 192, N = 307).
+// The 64x64-tile split-K kernel above covers such an output with 15 tiles, i.e. every K chunk of A is read 5 times and of B 3
+// times through L2, for 15 MFMAs of 32x32x2 per 4 LDS operand reads: 0.80 ms = 37 TFLOP/s at batch 2048, 40 % of the step.
+// Here a workgroup (4 waves) takes one K chunk and the WHOLE M extent for an 80-column slice of N: A is staged once per chunk
+// and slice (4 slices at N = 307), B once; a wave owns 3 x 5 tiles of 16x16 (v_mfma_f32_16x16x4_f32: 15 MFMAs per 8 operand
+// reads, 60 accumulator registers).  Both operands are row-contiguous in memory ([k][m], [k][n]) and keep that layout in LDS
+// (pitch = 16 mod 32 floats: the four k rows of a step land on different banks), two stage buffers of 32 nodes, one barrier per
+// stage.  Slabs as before: block (chunk z, slice q) writes its partial product into slab z; the gradient un-pack sums the slabs
+// in fixed order.
+constexpr int TT_M = 192, TT_NS = 80, TT_BK = 32;
+constexpr int TT_LDA = TT_M + 16, TT_LDB = TT_NS;  // both = 16 mod 32
+constexpr int TT_STAGE = TT_BK * (TT_LDA + TT_LDB);  // floats per stage buffer
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+struct TallProblem {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t slab_stride;
+  int M, N, K, lda, ldb, ldc, n_real, aug_ones;
+  int ksplit, kchunk, nslices, block_start;
+};
+struct TallBatch {
+  int n;
+  TallProblem p[GEMM_MAX_PROB];
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_tall_kernel(const TallBatch tb) {
+  extern __shared__ __attribute__((aligned(16))) float tt_lds[];  // [2][TT_STAGE]
+  int pi = 0;
+  while (pi + 1 < tb.n && (int)blockIdx.x >= tb.p[pi + 1].block_start) ++pi;
+  const TallProblem& P = tb.p[pi];
+  const int local = (int)blockIdx.x - P.block_start;
+  const int z = local / P.nslices, q = local - z * P.nslices;
+  const int n0 = q * TT_NS;
+  const int kbeg = z * P.kchunk, kend = min(P.K, kbeg + P.kchunk);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kq = lane >> 4;
+
+  f32x4t acc[3][5];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) acc[r][c] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+
+  // stage loads: A 32 x 192 floats = 1536 float4 (6 per thread), B 32 x 80 floats = 1280 float2 (5 per thread)
+  float4 ra[6];
+  float2 rb[5];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int s = tid + i * 256;
+      const int k = s / 48, m4 = (s - k * 48) * 4;
+      const int gk = min(k0 + k, kend - 1);               // clamped: masked when stored
+      const int mc = m4 < P.M ? m4 : 0;                   // M is a multiple of 4 (checked by the host)
+      ra[i] = *reinterpret_cast<const float4*>(P.A + (int64_t)gk * P.lda + mc);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int s = tid + i * 256;
+      const int k = s / 40, n2 = (s - k * 40) * 2;
+      const int gk = min(k0 + k, kend - 1);
+      const int col = n0 + n2;
+      const int cc = col + 1 < P.n_real ? col : 0;        // a pair that reaches past the real columns is rebuilt below
+      rb[i] = *reinterpret_cast<const float2*>(P.B + (int64_t)gk * P.ldb + cc);
+    }
+  };
+  auto put = [&](int k0, float* buf) {
+    float* As = buf;
+    float* Bs = buf + TT_BK * TT_LDA;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int s = tid + i * 256;
+      const int k = s / 48, m4 = (s - k * 48) * 4;
+      const bool live = k0 + k < kend && m4 < P.M;
+      *reinterpret_cast<float4*>(As + k * TT_LDA + m4) = live ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int s = tid + i * 256;
+      const int k = s / 40, n2 = (s - k * 40) * 2;
+      const bool klive = k0 + k < kend;
+      const int col = n0 + n2;
+      float2 v = rb[i];
+      if (col + 1 >= P.n_real) {  // the last real column, the ones column, padding
+        const float x0 = col < P.n_real ? P.B[(int64_t)min(k0 + k, kend - 1) * P.ldb + col] : ((P.aug_ones && col == P.n_real) ? 1.f : 0.f);
+        const float x1 = (P.aug_ones && col + 1 == P.n_real) ? 1.f : 0.f;
+        v = make_float2(x0, x1);
+      }
+      *reinterpret_cast<float2*>(Bs + k * TT_LDB + n2) = klive ? v : make_float2(0.f, 0.f);
+    }
+  };
+  const int nst = (kend - kbeg + TT_BK - 1) / TT_BK;
+  if (nst > 0) {
+    load(kbeg);
+    put(kbeg, tt_lds);
+  }
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    float* cur = tt_lds + (s & 1) * TT_STAGE;
+    if (s + 1 < nst) load(kbeg + (s + 1) * TT_BK);
+    const float* As = cur + kq * TT_LDA + w * 48 + i16;        // wave w: rows 48 w .. 48 w + 47 of the output
+    const float* Bs = cur + TT_BK * TT_LDA + kq * TT_LDB + i16;
+#pragma unroll
+    for (int ks = 0; ks < TT_BK / 4; ++ks) {
+      float av[3], bv[5];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) av[r] = As[ks * 4 * TT_LDA + r * 16];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) bv[c] = Bs[ks * 4 * TT_LDB + c * 16];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[c], acc[r][c], 0, 0, 0);
+    }
+    if (s + 1 < nst) put(kbeg + (s + 1) * TT_BK, tt_lds + ((s + 1) & 1) * TT_STAGE);
+    __syncthreads();
+  }
+  // D layout of a 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
+  float* C = P.C + (int64_t)z * P.slab_stride;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int col = n0 + c * 16 + i16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = w * 48 + r * 16 + 4 * kq + e;
+        if (row < P.M && col < P.N) C[(int64_t)row * P.ldc + col] = acc[r][c][e];
+      }
+    }
+}
+
+// problems of a split-K launch the tall kernel takes
+static bool tall_takes(const GemmProblem& p) {
+  const char* v = getenv("HMP_GEMM_TALL");  // 0: the tiled split-K kernel for every weight gradient (tests compare the two)
+  if (v && v[0] == '0') return false;
+  return p.trans_a && !p.trans_b && p.M > 0 && p.M <= TT_M && (p.M & 3) == 0 && p.N > 0 && p.K >= 32768 && (p.lda & 3) == 0 && (p.ldb & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 7) == 0 && p.epi == EPI_NONE &&
+         (p.n_real & 1) == 0;
+}
+
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm: %d problems", gb.n);
+  if (want_split) {  // weight gradients over >= 32768 nodes with <= 192 stacked columns: the tall kernel (one launch for all of them)
+    TallBatch tb;
+    memset(&tb, 0, sizeof(tb));
+    GemmBatch rest;
+    memset(&rest, 0, sizeof(rest));
+    int idx_t[GEMM_MAX_PROB], idx_r[GEMM_MAX_PROB];
+    double work_total = 0.0;
+    for (int i = 0; i < gb.n; ++i)
+      if (tall_takes(gb.p[i])) work_total += (double)gb.p[i].K * cdiv(gb.p[i].N, TT_NS);
+    for (int i = 0; i < gb.n; ++i) {
+      const GemmProblem& g = gb.p[i];
+      if (!tall_takes(g)) {
+        idx_r[rest.n] = i;
+        rest.p[rest.n++] = g;
+        continue;
+      }
+      TallProblem& P = tb.p[tb.n];
+      idx_t[tb.n++] = i;
+      P.A = g.A; P.B = g.B; P.C = g.C; P.slab_stride = g.slab_stride;
+      P.M = g.M; P.N = g.N; P.K = g.K; P.lda = g.lda; P.ldb = g.ldb; P.ldc = g.ldc; P.n_real = g.n_real; P.aug_ones = g.aug_ones;
+      P.nslices = cdiv(g.N, TT_NS);
+      // ~2 workgroups per CU over the whole launch, shared out in proportion to chunks x slices; <= GEMM_TALL_SLABS slabs
+      // (measured at batch 2048: 256 / 512 / 768 / 1024 workgroups -> 0.80 / 0.51 / 0.58 / 0.52 ms for the backward GEMMs)
+      int ks = (int)(512.0 * ((double)g.K * P.nslices / work_total) / P.nslices + 0.5);
+      if (ks > GEMM_TALL_SLABS) ks = GEMM_TALL_SLABS;
+      if (ks < 1) ks = 1;
+      int kchunk = cdiv(cdiv(g.K, ks), TT_BK) * TT_BK;
+      ks = cdiv(g.K, kchunk);
+      P.ksplit = ks; P.kchunk = kchunk;
+    }
+    if (tb.n > 0) {
+      int start = 0;
+      for (int i = 0; i < tb.n; ++i) {
+        tb.p[i].block_start = start;
+        start += tb.p[i].ksplit * tb.p[i].nslices;
+        gb.p[idx_t[i]].ksplit = tb.p[i].ksplit;
+        gb.p[idx_t[i]].kchunk = tb.p[i].kchunk;
+      }
+      static const int rc = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   2 * TT_STAGE * (int)sizeof(float)) == hipSuccess ? 0 : 1;
+      }();
+      HMP_CHECK_ARG(rc == 0, "gemm: could not raise the dynamic LDS limit of the tall weight-gradient kernel");
+      hipLaunchKernelGGL(gemm_tn_tall_kernel, dim3(start), dim3(256), 2 * TT_STAGE * sizeof(float), st, tb);
+      HMP_LAUNCH_CHECK();
+      if (rest.n == 0) return HMP_OK;
+      const int rc2 = gemm_launch(rest, want_split, max_slabs, st);  // (tall_takes is false for every problem of `rest`)
+      for (int i = 0; i < rest.n; ++i) {
+        gb.p[idx_r[i]].ksplit = rest.p[i].ksplit;
+        gb.p[idx_r[i]].kchunk = rest.p[i].kchunk;
+      }
+      return rc2;
+    }
+  }
   int64_t tiles64 = 0;
   double work = 0.0;
   int max_k = 0;

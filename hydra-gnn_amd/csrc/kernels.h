@@ -37,6 +37,7 @@ struct GemmProblem {
 };
 
 constexpr int GEMM_MAX_PROB = 8;
+constexpr int GEMM_TALL_SLABS = 192;  // split-K slabs the tall weight-gradient kernel may ask for (== net.hip: MAX_SLABS, the slab buffer's size)
 struct GemmBatch {
   int n;
   int total_tiles;

@@ -56,6 +56,7 @@ struct LayerLayout {
 };
 
 constexpr int MAX_SLABS = 192;       // split-K slabs per weight-gradient problem (large batches: 256x256 tiles x ~170 node chunks)
+static_assert(MAX_SLABS >= GEMM_TALL_SLABS, "the slab buffer must hold what the tall weight-gradient kernel may write");
 constexpr int TN_DIRECT_SLABS = 16;  // small batches: more slabs only lengthen the gradient un-pack
 
 struct ProfRec {

@@ -434,12 +434,15 @@ def test_bf16_mode_htree_many_edge_types():
         assert float((gout[k] - gr).norm() / (gr.norm() + 1e-20)) < 0.1, k
 
 
-def test_standalone_sequence_at_the_reference_batch_scale_matches_the_oracle(monkeypatch):
+@pytest.mark.parametrize("tall,hidden", [("1", 64), ("0", 64), ("1", 48)])
+def test_standalone_sequence_at_the_reference_batch_scale_matches_the_oracle(monkeypatch, tall, hidden):
     """config/mp3d/*.yaml train with batch_size 2048 (~190 000 nodes): far above the small-batch threshold, i.e. the stand-alone
     launch sequence (grouped fp32 MFMA GEMMs + one-row-group aggregation, hidden 64).  At 512 graphs (46 000 nodes, a size the
-    float64 oracle holds) with that sequence pinned: logits, loss and every gradient at the north_star tolerance."""
+    float64 oracle holds) with that sequence pinned: logits, loss and every gradient at the north_star tolerance.  The weight
+    gradients over the 45 000 objects run on the tall split-K kernel (HMP_GEMM_TALL=0: the 64x64-tile one)."""
     monkeypatch.setenv("HMP_FUSE", "0")
-    ora, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork, seed=4)
+    monkeypatch.setenv("HMP_GEMM_TALL", tall)
+    ora, net = build(dict(SAGE_KW, hidden_dim=hidden), HeterogeneousNetwork, omodels.HeterogeneousNetwork, seed=4)
     batch = workloads.config2_batch(512)
     o64 = copy.deepcopy(ora).double().eval()
     b64 = batch.to("cpu")
