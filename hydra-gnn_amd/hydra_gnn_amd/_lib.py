@@ -201,8 +201,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.hmp_abi_version() != 1:
-        raise HydraMPError(f"ABI version mismatch: library {lib.hmp_abi_version()}, binding 1")
+    if lib.hmp_abi_version() != 2:
+        raise HydraMPError(f"ABI version mismatch: library {lib.hmp_abi_version()}, binding 2")
     for i, st in enumerate(_STRUCTS):
         if lib.hmp_sizeof(i) != C.sizeof(st):
             raise HydraMPError(f"struct layout mismatch for {st.__name__}: C {lib.hmp_sizeof(i)} vs ctypes {C.sizeof(st)}")

@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define HMP_ABI_VERSION 1
+/* 2: round 2 -- hmp_batch grew (plan_valid, d_node_ptr, n_graphs, max_graph_nodes, d_edge_ptr), hmp_train_args::d_step; sections 10-12 */
+#define HMP_ABI_VERSION 2
 
 #define HMP_OK 0
 #define HMP_E_ARG 1      /* bad argument (shape / alignment / capacity) */

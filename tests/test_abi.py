@@ -23,7 +23,7 @@ def declared_functions():
 def test_library_exists_and_loads_without_gpu():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.hmp_abi_version() == 1
+    assert lib.hmp_abi_version() == 2
 
 
 def test_every_declared_symbol_is_exported_and_bound():
