@@ -662,12 +662,12 @@ static int ws_launch(const GemmProblem& p, hipStream_t st) {
     const char* dv = getenv("HMP_WS_DBG");
     a.dbg = dv ? atoi(dv) : 0;
   }
-  int n_cu = 256;
-  {
+  static const int n_cu = [] {  // (queried once: the property call is not cheap)
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
+    return 256;
+  }();
   // groups in sets of 8 (one per XCD); as many sets as fit the chip, at least one
   int sets = WS_PER_CU * n_cu / (8 * a.n_slices);
   if (sets < 1) sets = 1;
