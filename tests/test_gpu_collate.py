@@ -124,6 +124,14 @@ def test_batch_stream_one_launch_collation_is_bit_identical(batch_size, n_graphs
             if "edge_attr" in ref[e]:
                 assert torch.equal(got[e].edge_attr.cpu(), ref[e].edge_attr), (it, e)
         assert int(h.c.n_out) == ref["rooms"].x.size(0)
+        # the offset tables the stream hands to the plan build (hmp_batch::d_node_ptr / d_edge_ptr) are collate's ptr vectors
+        B = len(ids)
+        off = stream._offsets.view(-1, stream._off_stride).cpu()
+        for t in ref.node_types:
+            assert torch.equal(off[stream._slot_of[t], :B + 1], ref[t].ptr), (it, t)
+        for e in ref.edge_types:
+            assert torch.equal(off[stream._slot_of[e], :B + 1], ref[e].ptr), (it, e)
+        assert int(h.c.n_graphs) == B
 
 
 def test_batch_stream_drives_the_native_step_like_host_collated_batches():
