@@ -16,6 +16,7 @@
 namespace hmp {
 
 KT_DEFINE(agg)
+KT_BLOCKS_DEFINE(agg)
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 constexpr int WIN_THREADS_CHAIN = 512;   // graph-local chain kernel: CHAIN_GROUPS groups of 256 threads (1024 threads would cap the
@@ -504,11 +505,13 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a) {
   while (ti + 1 < a.n && (int)blockIdx.x >= a.bstart[ti + 1]) ++ti;
   karg_warm<9>((int)offsetof(AggArgs, d) + ti * (int)sizeof(AggDst), (int)sizeof(AggDst));
   const AggDst& D = a.d[ti];
-  const int rpb = 256 / GS;
+  // rows per workgroup: 256 / GS, or 8 for an entry of heavy rows in a small launch (AggDst::tile_rows; the other row groups idle)
+  const int rpb = (D.tile_rows == 8 && 256 / GS > 8) ? 8 : 256 / GS;
   int local = blockIdx.x - D.block_start;
   // workgroups go to the 8 XCDs round robin by block id: give XCD x the x-th contiguous eighth of the rows, so that the
   // neighbour rows a run of consecutive destinations shares (scene graphs: the same room) are fetched into ONE L2, not 8
   if (a.xcd) local = (local & 7) * ((cdiv_dev(D.n_rows, rpb) + 7) >> 3) + (local >> 3);
+  if ((int)threadIdx.x / GS >= rpb) return;
   int row = local * rpb + threadIdx.x / GS;
   // GS = 64: the wavefront IS the row group, so the row (and with it every extent / neighbour id) is wave-uniform; saying so
   // moves those loads and the address arithmetic to the scalar unit
@@ -625,13 +628,17 @@ __device__ __forceinline__ void agg_proj_tile(const AggArgs& a, const AggDst& D,
 template <int GS>
 __global__ __launch_bounds__(256, GS >= 32 ? 2 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
   __shared__ float Hs[256 * 17];
+  KT_BLOCK_BEGIN();
   KT_SPAN_BEGIN(40);
   int ti = 0;
   while (ti + 1 < a.n && (int)blockIdx.x >= a.bstart[ti + 1]) ++ti;
   karg_warm<9>((int)offsetof(AggArgs, d) + ti * (int)sizeof(AggDst), (int)sizeof(AggDst));
   const AggDst& D = a.d[ti];
-  agg_proj_tile<GS>(a, D, ((int)blockIdx.x - D.block_start) * 16, D.n_rows, true, Hs);
+  // (an entry of heavy rows is cut into tiles of 8: see AggDst::tile_rows)
+  const int row0 = ((int)blockIdx.x - D.block_start) * D.tile_rows;
+  agg_proj_tile<GS>(a, D, row0, min(row0 + D.tile_rows, D.n_rows), true, Hs);
   KT_SPAN_END(40, ti);
+  KT_BLOCK_END();
 }
 
 // fixed-order sum of the per-row {loss, valid} pairs -> {loss_sum, count}; run by ONE block (256 threads)
@@ -810,9 +817,10 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const TAggArgs a) {
   while (si + 1 < a.n && (int)blockIdx.x >= a.bstart[si + 1]) ++si;
   karg_warm<10>((int)offsetof(TAggArgs, s) + si * (int)sizeof(TAggSrc), (int)sizeof(TAggSrc));
   const TAggSrc& S = a.s[si];
-  const int rpb = 256 / GS;
+  const int rpb = (S.tile_rows == 8 && 256 / GS > 8) ? 8 : 256 / GS;  // see agg_fwd_kernel
   int local = blockIdx.x - S.block_start;
   if (a.xcd) local = (local & 7) * ((cdiv_dev(S.n_rows, rpb) + 7) >> 3) + (local >> 3);  // see agg_fwd_kernel
+  if ((int)threadIdx.x / GS >= rpb) return;
   int row = local * rpb + threadIdx.x / GS;
   if (GS == 64) row = __builtin_amdgcn_readfirstlane(row);  // wave-uniform, see agg_fwd_kernel
   if (row >= S.n_rows) return;
@@ -1036,7 +1044,8 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   while (si + 1 < a.n && (int)blockIdx.x >= a.bstart[si + 1]) ++si;
   karg_warm<10>((int)offsetof(TAggArgs, s) + si * (int)sizeof(TAggSrc), (int)sizeof(TAggSrc));
   const TAggSrc& S = a.s[si];
-  agg_bwd_dx_tile<GS>(a, S, ((int)blockIdx.x - S.block_start) * 16, S.n_rows, true, Hs);
+  const int row0 = ((int)blockIdx.x - S.block_start) * S.tile_rows;  // (tiles of 8 for entries of heavy rows: AggDst::tile_rows)
+  agg_bwd_dx_tile<GS>(a, S, row0, min(row0 + S.tile_rows, S.n_rows), true, Hs);
   KT_SPAN_END(48, si);
 }
 
@@ -1828,7 +1837,8 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
     AggDst& D = a.d[i];
     HMP_CHECK_ARG((D.ldo & 3) == 0 && (D.F & 3) == 0, "agg_fwd: widths must be padded to 4");
     D.block_start = blocks;
-    const int nb = cdiv(D.n_rows, 256 / gs);
+    if (a.xcd || a.zb16) D.tile_rows = 0;  // (tiles of 8 rows are a small-launch device)
+    const int nb = cdiv(D.n_rows, (D.tile_rows == 8 && 256 / gs > 8) ? 8 : 256 / gs);
     blocks += a.xcd ? ((nb + 7) & ~7) : nb;  // xcd: every entry starts at a multiple of 8 and owns whole groups of 8 blocks
   }
   a.total_blocks = blocks;
@@ -1906,8 +1916,9 @@ int agg_proj_fwd_launch(AggArgs& a, hipStream_t st) {
     if (D.pw)
       HMP_CHECK_ARG((D.pK & 15) == 0 && D.pK <= 256 && D.pK <= D.F && (D.pldw & 3) == 0 && D.pncols > 0,
                     "agg_proj_fwd: projection K %d / ld %d not supported", D.pK, D.pldw);
+    if (D.tile_rows != 8) D.tile_rows = 16;
     D.block_start = blocks;
-    blocks += cdiv(D.n_rows, 16);
+    blocks += cdiv(D.n_rows, D.tile_rows);
   }
   a.total_blocks = blocks;
   if (blocks == 0) return HMP_OK;
@@ -1939,7 +1950,8 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
   a.xcd = (rows_total >= AGG_XCD_ROWS && agg_xcd_enabled()) ? 1 : 0;
   for (int i = 0; i < a.n; ++i) {
     a.s[i].block_start = blocks;
-    const int nb = cdiv(a.s[i].n_rows, 256 / gs);
+    if (a.xcd || a.gb16) a.s[i].tile_rows = 0;  // (tiles of 8 rows are a small-launch device)
+    const int nb = cdiv(a.s[i].n_rows, (a.s[i].tile_rows == 8 && 256 / gs > 8) ? 8 : 256 / gs);
     blocks += a.xcd ? ((nb + 7) & ~7) : nb;
   }
   a.total_blocks = blocks;
@@ -2016,8 +2028,9 @@ int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st) {
   int gs = 16;
   while (gs < 64 && gs * 4 < Fmax) gs <<= 1;
   for (int i = 0; i < a.n; ++i) {
+    if (a.s[i].tile_rows != 8) a.s[i].tile_rows = 16;
     a.s[i].block_start = blocks;
-    blocks += cdiv(a.s[i].n_rows, 16);
+    blocks += cdiv(a.s[i].n_rows, a.s[i].tile_rows);
   }
   a.total_blocks = blocks;
   if (blocks == 0 && !a.fin_row_lv) return HMP_OK;

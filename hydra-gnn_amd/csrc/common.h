@@ -102,6 +102,20 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
       atomicMax(&kt_buf[(i) + 2 + (sub)], kt_now - kt_span_t0);           \
     }                                                                     \
   } while (0)
+// per-workgroup life of one launch: (start, end) of workgroup b into a second, larger buffer (first 1024 workgroups)
+#define KT_BLOCKS_DEFINE(tag)                                                                            \
+  static __device__ unsigned long long kt_blk[2048];                                                     \
+  extern "C" int hmp_debug_ktime_##tag##_blocks(unsigned long long* out) {                               \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_blk), sizeof(kt_blk)) == hipSuccess ? 0 : 1;           \
+  }
+#define KT_BLOCK_BEGIN()                                                          \
+  do {                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) kt_blk[2 * blockIdx.x] = wall_clock64(); \
+  } while (0)
+#define KT_BLOCK_END()                                                            \
+  do {                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) kt_blk[2 * blockIdx.x + 1] = wall_clock64(); \
+  } while (0)
 // stamp once every vector load issued so far has landed
 #define KTW(i)                                   \
   do {                                           \
@@ -125,6 +139,13 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
   } while (0)
 #define KTW(i) \
   do {         \
+  } while (0)
+#define KT_BLOCKS_DEFINE(tag)
+#define KT_BLOCK_BEGIN() \
+  do {                   \
+  } while (0)
+#define KT_BLOCK_END() \
+  do {                 \
   } while (0)
 #define KT_SPAN_BEGIN(i) \
   do {                   \

@@ -189,6 +189,9 @@ struct AggDst {
   float* ce_grad;
   float* ce_row_lv;
   int win_in, win_src_rows;  // filled by agg_fwd_launch: in-conv served from the LDS window (-1: none), rows of its source
+  int tile_rows;             // agg_proj_fwd_launch: rows per workgroup, 16 or 8.  A launch is as long as its slowest tile and a tile of
+                             // high-degree rows (rooms: ~12 objects each) requests twice the lines of the others (tools/ktime_blocks.py:
+                             // 7.3 us against 5.8 us): such entries are cut into twice as many tiles of 8 rows (there are idle CUs)
   AggIn in[AGG_MAX_IN];
 };
 struct AggArgs {
@@ -235,6 +238,7 @@ struct TAggSrc {
   int xldw, xN, xldg, xldh, xact, xdrop_on;
   float xscale;
   int win_out, win_dst_rows;  // filled by agg_bwd_launch (see AggDst::win_in)
+  int tile_rows;              // agg_bwd_dx_launch: rows per workgroup, 16 or 8 (see AggDst::tile_rows)
   TAggOut out[AGG_MAX_IN];
 };
 struct TAggArgs {

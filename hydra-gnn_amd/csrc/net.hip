@@ -1155,6 +1155,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           I.same_type = C.src == C.dst ? 1 : 0;
           I.n_src = b->n_nodes[C.src];
           I.ell = ell_use(n) ? n->ell[C.edge_type] : nullptr;
+          if (n->fuse_now && b->n_edges[C.edge_type] > (int64_t)8 * b->n_nodes[C.dst]) D.tile_rows = 8;  // average in-degree > 8
         }
       }
       // fuse the projection of layer l+1 when every node type it reads is produced right here
@@ -1334,6 +1335,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           O.same_type = C.src == C.dst ? 1 : 0;
           O.n_dst = b->n_nodes[C.dst];
           O.t_ell = ell_use(n) ? n->t_ell[C.edge_type] : nullptr;
+          if (n->fuse_now && b->n_edges[C.edge_type] > (int64_t)8 * b->n_nodes[C.src]) T.tile_rows = 8;  // average out-degree > 8
         }
       }
       // input gradient of layer l inside the same kernel (row-local GEMM on 16-row tiles) for small batches
