@@ -74,6 +74,10 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
 #ifdef HMP_KTIME
 #define KT_DEFINE(tag)                                                                                   \
   static __device__ unsigned long long kt_buf[64];                                                       \
+  static __device__ int kt_sel = 0; /* the workgroup that stamps (hmp_debug_ktime_<tag>_select) */        \
+  extern "C" int hmp_debug_ktime_##tag##_select(int blk) {                                               \
+    return hipMemcpyToSymbol(HIP_SYMBOL(kt_sel), &blk, sizeof(int)) == hipSuccess ? 0 : 1;               \
+  }                                                                                                      \
   extern "C" int hmp_debug_ktime_##tag(unsigned long long* out) {                                        \
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_buf), sizeof(kt_buf)) == hipSuccess ? 0 : 1;           \
   }                                                                                                      \
@@ -82,7 +86,7 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
   }
 #define KT(i)                                                                      \
   do {                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = wall_clock64();           \
+    if (threadIdx.x == 0 && (int)blockIdx.x == kt_sel) kt_buf[i] = wall_clock64();  \
   } while (0)
 // span of a launch over ALL its workgroups: slot i = earliest start, i + 1 = latest end, i + 2 + sub = longest workgroup of kind sub (thread 0 of
 // every workgroup; the host presets the slots: hmp_debug_ktime_<tag>_set)
@@ -126,11 +130,11 @@ __device__ __forceinline__ void karg_warm(int off, int bytes) {
 #define KT_NOW() wall_clock64()
 #define KT_ADD(i, t0)                                                               \
   do {                                                                              \
-    if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] += wall_clock64() - (t0);    \
+    if (threadIdx.x == 0 && (int)blockIdx.x == kt_sel) kt_buf[i] += wall_clock64() - (t0); \
   } while (0)
 #define KT_ZERO(i)                                                 \
   do {                                                             \
-    if (threadIdx.x == 0 && blockIdx.x == 0) kt_buf[i] = 0;        \
+    if (threadIdx.x == 0 && (int)blockIdx.x == kt_sel) kt_buf[i] = 0; \
   } while (0)
 #else
 #define KT_DEFINE(tag)

@@ -55,6 +55,23 @@ def main():
         print(f"XCD {x}: start median {np.median(start[idx]):.2f}  duration median {np.median(dur[idx]):.2f} max {dur[idx].max():.2f}  end max {end[idx].max():.2f}")
     order = np.argsort(-end)[:8]
     print("last to finish:", [(int(b), f"start {start[b]:.2f}", f"dur {dur[b]:.2f}") for b in order])
+    # phase stamps of one object tile and one room tile (KT(0): tile start, KT(3..7): inside agg_row of the tile's first row group,
+    # KT(1): gather done and tile in LDS, KT(2): projection stored)
+    sel = lib.hmp_debug_ktime_agg_select
+    sel.argtypes = [C.c_int]
+    get = lib.hmp_debug_ktime_agg
+    get.argtypes = [C.POINTER(C.c_ulonglong)]
+    for name, blk in (("object tile 0", 0), ("room tile", n_obj + 2)):
+        assert sel(blk) == 0
+        for _ in range(3):
+            step(batch, y)
+        torch.cuda.synchronize()
+        b64 = (C.c_ulonglong * 64)()
+        assert get(b64) == 0
+        v = list(b64)
+        slots = [0, 3, 4, 5, 6, 7, 1, 2]
+        print(f"{name:14s}", " ".join(f"[{i}]+{(v[i] - v[0]) / 100.0:5.2f}" for i in slots))
+    sel(0)
 
 
 if __name__ == "__main__":
