@@ -199,7 +199,8 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
   if (blk < a.gemm_blocks) {
     KT(0);
     int pi = 0;
-    while (pi + 1 < a.n_prob && blk >= a.prob[pi + 1].blk_start) ++pi;
+    while (pi + 1 < a.n_prob && blk >= a.prob_start[pi + 1]) ++pi;
+    karg_warm<(sizeof(FrontProb) + 63) / 64 + 1>((int)offsetof(FrontArgs, prob) + pi * (int)sizeof(FrontProb), (int)sizeof(FrontProb));
     const FrontProb& P = a.prob[pi];
     const int local = blk - P.blk_start;
     // column tiles of one row tile are adjacent block ids (same A rows: L2 / MALL reuse)
@@ -268,6 +269,7 @@ int front_launch(FrontArgs& a, hipStream_t st) {
     P.tiles_m = cdiv(P.M, FT);
     P.tiles_n = cdiv(P.N, FT);
     P.blk_start = start;
+    a.prob_start[i] = start;
     start += P.tiles_m * P.tiles_n;
   }
   a.gemm_blocks = start;

@@ -88,6 +88,7 @@ struct FrontArgs {
   const int2* pack_map;  // per pack block: {segment, first item}; 16 items (packed row, 64-column chunk) per block
   float* packed;
   int* step_ctr;         // non-null: the pack role's first block bumps this device step counter
+  int prob_start[FR_MAX_PROB];  // prob[i].blk_start again, next to the header fields (front_launch fills it): see karg_warm (common.h)
   int part_start[2 * HMP_MAX_EDGE_TYPES + 1];
   int rows_per_part[2 * HMP_MAX_EDGE_TYPES];
   FrontJob job[HMP_MAX_EDGE_TYPES];
