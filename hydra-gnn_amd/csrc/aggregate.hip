@@ -626,7 +626,7 @@ __device__ __forceinline__ void agg_proj_tile(const AggArgs& a, const AggDst& D,
 }
 
 template <int GS>
-__global__ __launch_bounds__(256, GS >= 32 ? 2 : 1) void agg_proj_fwd_kernel(const AggArgs a) {
+__global__ __launch_bounds__(256, GS == 32 ? 3 : (GS == 64 ? 2 : 1)) void agg_proj_fwd_kernel(const AggArgs a) {
   __shared__ float Hs[256 * 17];
   KT_BLOCK_BEGIN();
   KT_SPAN_BEGIN(40);
@@ -1816,6 +1816,7 @@ static int agg_win_out(const TAggSrc& S) {
   return -1;
 }
 
+constexpr int AGG_SMALL_TILES = 224;  // 16-row tiles of a launch up to which heavy entries are cut into tiles of 8 (AggDst::tile_rows)
 // the compact copy of the entries' first blocks that the kernels search (AggArgs::bstart)
 static inline void sync_bstart(AggArgs& a) {
   for (int i = 0; i < a.n; ++i) a.bstart[i] = a.d[i].block_start;
@@ -1837,7 +1838,7 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
     AggDst& D = a.d[i];
     HMP_CHECK_ARG((D.ldo & 3) == 0 && (D.F & 3) == 0, "agg_fwd: widths must be padded to 4");
     D.block_start = blocks;
-    if (a.xcd || a.zb16) D.tile_rows = 0;  // (tiles of 8 rows are a small-launch device)
+    if (a.xcd || a.zb16 || rows_total > 16 * AGG_SMALL_TILES) D.tile_rows = 0;  // (tiles of 8 rows are a small-launch device)
     const int nb = cdiv(D.n_rows, (D.tile_rows == 8 && 256 / gs > 8) ? 8 : 256 / gs);
     blocks += a.xcd ? ((nb + 7) & ~7) : nb;  // xcd: every entry starts at a multiple of 8 and owns whole groups of 8 blocks
   }
@@ -1906,6 +1907,10 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
 int agg_proj_fwd_launch(AggArgs& a, hipStream_t st) {
   int Fmax = 0, blocks = 0;
   for (int i = 0; i < a.n; ++i) Fmax = a.d[i].F > Fmax ? a.d[i].F : Fmax;
+  // tiles of 8 rows for heavy entries only while the launch leaves CUs idle (more workgroups in a launch of several rounds only add rounds)
+  int tiles16 = 0;
+  for (int i = 0; i < a.n; ++i) tiles16 += cdiv(a.d[i].n_rows, 16);
+  const bool small_launch = tiles16 <= AGG_SMALL_TILES;
   if (a.n == 0 || Fmax == 0) return HMP_OK;
   HMP_CHECK_ARG(Fmax <= 256, "agg_proj_fwd: row width %d > 256", Fmax);
   int gs = 16;
@@ -1916,7 +1921,7 @@ int agg_proj_fwd_launch(AggArgs& a, hipStream_t st) {
     if (D.pw)
       HMP_CHECK_ARG((D.pK & 15) == 0 && D.pK <= 256 && D.pK <= D.F && (D.pldw & 3) == 0 && D.pncols > 0,
                     "agg_proj_fwd: projection K %d / ld %d not supported", D.pK, D.pldw);
-    if (D.tile_rows != 8) D.tile_rows = 16;
+    if (D.tile_rows != 8 || !small_launch) D.tile_rows = 16;
     D.block_start = blocks;
     blocks += cdiv(D.n_rows, D.tile_rows);
   }
@@ -1950,7 +1955,7 @@ int agg_bwd_launch(TAggArgs& a, hipStream_t st) {
   a.xcd = (rows_total >= AGG_XCD_ROWS && agg_xcd_enabled()) ? 1 : 0;
   for (int i = 0; i < a.n; ++i) {
     a.s[i].block_start = blocks;
-    if (a.xcd || a.gb16) a.s[i].tile_rows = 0;  // (tiles of 8 rows are a small-launch device)
+    if (a.xcd || a.gb16 || rows_total > 16 * AGG_SMALL_TILES) a.s[i].tile_rows = 0;  // (tiles of 8 rows are a small-launch device)
     const int nb = cdiv(a.s[i].n_rows, (a.s[i].tile_rows == 8 && 256 / gs > 8) ? 8 : 256 / gs);
     blocks += a.xcd ? ((nb + 7) & ~7) : nb;
   }
@@ -2027,8 +2032,11 @@ int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st) {
   HMP_CHECK_ARG(Fmax <= 256 && kmax <= 896, "agg_bwd_dx: segment width %d / stacked width %d not supported", Fmax, kmax);
   int gs = 16;
   while (gs < 64 && gs * 4 < Fmax) gs <<= 1;
+  int tiles16 = 0;
+  for (int i = 0; i < a.n; ++i) tiles16 += cdiv(a.s[i].n_rows, 16);
+  const bool small_launch = tiles16 <= AGG_SMALL_TILES;  // see agg_proj_fwd_launch
   for (int i = 0; i < a.n; ++i) {
-    if (a.s[i].tile_rows != 8) a.s[i].tile_rows = 16;
+    if (a.s[i].tile_rows != 8 || !small_launch) a.s[i].tile_rows = 16;
     a.s[i].block_start = blocks;
     blocks += cdiv(a.s[i].n_rows, a.s[i].tile_rows);
   }
