@@ -183,3 +183,37 @@ def test_oracle_homogeneous_htree_network_matches_its_definition():
     x = LeafPool()(x, b.pool_edge_index)
     torch.testing.assert_close(m(b), x[b.room_mask])
     assert set(m.state_dict()) >= {"pre_mp.att_src", "pre_mp.att_dst", "pre_mp.lin_src.weight", "pre_mp.bias", "convs.0.lin_l.weight"}
+
+
+def test_collate_records_where_each_graph_starts():
+    """collate() keeps [PyG] Batch.ptr per node type and, per edge type, the offset of every graph's first edge (what PyG holds in
+    Batch._slice_dict): edges of graph g are entries [ptr[g], ptr[g+1]) and join nodes of graph g only -- the statement the plan
+    build of a small batch relies on (hmp_batch::d_node_ptr / d_edge_ptr).  A graph may lack nodes or edges of a type."""
+    gs = [workloads.mp3d_like_graph(np.random.Generator(np.random.PCG64(s))) for s in range(5)]
+    empty = HeteroData()  # two objects, no rooms, no edges; the same attribute set as the others
+    for t, n in (("objects", 2), ("rooms", 0)):
+        for k in gs[0][t].keys():
+            v = getattr(gs[0][t], k)
+            if isinstance(v, torch.Tensor):
+                setattr(empty[t], k, torch.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype))
+    for et in EDGE_TYPES:
+        empty[et].edge_index = torch.zeros(2, 0, dtype=torch.int64)
+    gs.insert(2, empty)
+    b = collate(gs)
+    for t in b.node_types:
+        counts = [g[t].num_nodes for g in gs]
+        assert b[t].ptr.tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
+    for et in b.edge_types:
+        counts = [g[et].edge_index.size(1) for g in gs]
+        ptr = b[et].ptr
+        assert ptr.dtype == torch.int64 and ptr.tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
+        src, _, dst = et
+        ei = b[et].edge_index
+        for g in range(len(gs)):  # every edge of the slice joins rows of graph g
+            sl = ei[:, int(ptr[g]):int(ptr[g + 1])]
+            if sl.numel():
+                assert int(sl[0].min()) >= int(b[src].ptr[g]) and int(sl[0].max()) < int(b[src].ptr[g + 1])
+                assert int(sl[1].min()) >= int(b[dst].ptr[g]) and int(sl[1].max()) < int(b[dst].ptr[g + 1])
+    assert b.max_graph_nodes == max(max(g[t].num_nodes for t in g.node_types) for g in gs)
+    del b[EDGE_TYPES[0]].ptr  # a caller that permutes an edge list drops the statement
+    assert "ptr" not in b[EDGE_TYPES[0]]
