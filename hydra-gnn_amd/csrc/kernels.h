@@ -147,6 +147,7 @@ size_t plan_scratch_ints(int64_t E, int n_src, int n_dst);
 // carve scratch for job (all int32); zero_begin/zero_ints return the region to memset
 void plan_carve(PlanJob& job, int* scratch);
 int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st);
+int plan_link_launch(PlanBatch& pb, hipStream_t st);  // t_pos only, after a single-launch build that ran elsewhere (front kernel)
 
 // ---------------------------------------------------------------------------------------------
 // K1 + fused SAGE aggregation

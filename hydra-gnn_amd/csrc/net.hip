@@ -837,14 +837,16 @@ void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb);
 // limits (the caller then launches pack, projection and plan separately).
 bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArgs& fa) {
   const char* fv = getenv("HMP_FRONT");  // 0: separate pack / projection / plan launches (tests)
-  if ((fv && fv[0] == '0') || n->any_gat || !n->d_pack_map) return false;
+  if ((fv && fv[0] == '0') || !n->d_pack_map) return false;
   const hmp_net_spec& S = n->spec;
   const hmp_layer_spec& Ls = S.layers[0];
   const LayerLayout& Y = n->lay[0];
-  if (Y.kind != HMP_CONV_SAGE) return false;
+  // GAT layers: the projection's operand is the pack's OUTPUT (att . W rows), so only plan and pack share the launch (the plan,
+  // 19 us at config 3, runs behind the 46 us pack); the link pass (t_pos) follows as its own launch
+  const bool proj = Y.kind == HMP_CONV_SAGE && !n->any_gat;
   memset(&fa, 0, sizeof(fa));
   // ---- projection problems
-  for (int s = 0; s < n->T; ++s) {
+  for (int s = 0; s < n->T && proj; ++s) {
     if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
     if (fa.n_prob == FR_MAX_PROB) return false;
     FrontProb& P = fa.prob[fa.n_prob++];
@@ -874,7 +876,7 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
       if (G.nsrc == 0) return false;
     }
   }
-  if (fa.n_prob == 0 || S.n_params >= ((int64_t)1 << 31)) return false;
+  if ((proj && fa.n_prob == 0) || S.n_params >= ((int64_t)1 << 31)) return false;
   // ---- plan parts
   PlanBatch pb;
   fill_plan_batch(n, b, pb);
@@ -882,7 +884,7 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
   for (int e = 0; e < pb.n; ++e) E += pb.j[e].E;
   if (E > PS_MAX_EDGES) return false;
   fa.n_jobs = pb.n;
-  fa.need_tpos = 0;
+  fa.need_tpos = pb.need_tpos;
   fa.plan_rc = plan_small_fits_rc(pb) ? 1 : 0;
   fa.plan_blocks = plan_small_layout(pb, fa.part_start, fa.rows_per_part);
   if (n->reuse_plan) fa.plan_blocks = 0;  // same topology as the previous call: no plan role in this launch
@@ -1053,6 +1055,11 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     Scope sc(n, KC_FRONT, main_st);
     HMP_TRY(front_launch(fa, main_st));
     if (fa.plan_blocks > 0) n->ell_ok = n->ell_on;  // the front kernel's plan role is the single-launch build
+    if (fa.need_tpos && fa.plan_blocks > 0) {
+      PlanBatch pb;
+      fill_plan_batch(n, b, pb);
+      HMP_TRY(plan_link_launch(pb, main_st));
+    }
     for (int e = 0; e < n->ET; ++e) {  // what run_plan records on the host
       hmp_plan& P = n->plan[e];
       P.n_src = b->n_nodes[S.edge_src[e]]; P.n_dst = b->n_nodes[S.edge_dst[e]]; P.n_edges = b->n_edges[e];
@@ -1067,7 +1074,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     LayerLayout& Y = n->lay[l];
     st = (l == 0) ? side : main_st;
     bool z16 = false;  // this layer's projected rows are stored as bf16 (decided with the projection, read by the aggregation)
-    if (l == 0 && front) {
+    if (l == 0 && front && fa.n_prob > 0) {
       // projection, plan and pack already ran in the front kernel
     } else if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
       HMP_TRY(chain_flush(n, st));

@@ -336,6 +336,19 @@ void plan_carve(PlanJob& job, int* s) {
   job.tmpc_out = s;
 }
 
+// the link pass alone (t_pos: CSR position of every CSC entry), for a plan whose single-launch build ran as a role of another
+// launch (front.hip) with need_tpos set
+int plan_link_launch(PlanBatch& pb, hipStream_t st) {
+  pb.edge_start[0] = 0;
+  for (int j = 0; j < pb.n; ++j) pb.edge_start[j + 1] = pb.edge_start[j] + pb.j[j].E;
+  const int64_t E = pb.edge_start[pb.n];
+  if (E <= 0) return HMP_OK;
+  const int lg = (int)(cdiv(E, 256) < 2048 ? cdiv(E, 256) : 2048);
+  hipLaunchKernelGGL(plan_link_kernel, dim3(lg), dim3(256), 0, st, pb);
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
+}
+
 int plan_launch(PlanBatch& pb, int* d_status, hipStream_t st) {
   HMP_CHECK_ARG(pb.n >= 0 && pb.n <= HMP_MAX_EDGE_TYPES, "plan: %d jobs", pb.n);
   if (pb.n == 0) return HMP_OK;
