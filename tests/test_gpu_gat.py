@@ -297,3 +297,34 @@ def test_homogeneous_gat_parity():
     ref = o64(Data(x=x.double(), edge_index=ei, room_mask=room_mask))
     out = net(d.to(DEV))
     torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("block", ["GAT", "GAT_edge"])
+def test_gat_front_launch_of_plan_and_pack_is_bit_identical(monkeypatch, block):
+    """GAT nets: plan parts and pack blocks share one front launch (no projection role -- its operand is the pack's output), the
+    link pass follows; HMP_FRONT=0 keeps pack, plan and link as separate launches.  Same plan, same packed operands: predictions,
+    gradients and three optimiser steps agree to the last bit."""
+    batch = workloads.config3_batch(6, edge=(block == "GAT_edge"))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HMP_FRONT", mode)
+        _, net = gat_pair(block, [16, 16], [2, 2, 2], [True, True, False], seed=3)
+        net.eval()
+        gb = batch.to(DEV)
+        pred = net(gb)
+        y = gb["rooms"].y
+        net.loss(pred, y, y != 25).backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        assert net.native().read_state()[1] == 0
+        net.train()
+        step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, use_graph=False)
+        for _ in range(3):
+            step(gb, y)
+        res[mode] = (pred.detach().clone(), grads, step.loss(), {k: p.detach().clone() for k, p in net.named_parameters()})
+    monkeypatch.delenv("HMP_FRONT")
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g in res["0"][1].items():
+        assert torch.equal(res["1"][1][k], g), k
+    assert res["1"][2] == res["0"][2]
+    for k, p0 in res["0"][3].items():
+        assert torch.equal(res["1"][3][k], p0), k
