@@ -77,6 +77,13 @@ def parse():
                     help="extra leg (config 2 / 3): every step takes a DIFFERENT batch, collated on the device from a resident "
                          "dataset of 64 x batch graphs (store.BatchStream: one host call + one kernel) and described afresh -- "
                          "the loop a trainer actually runs; reported as `fresh_batches` beside the headline")
+    ap.add_argument("--gat-edge", action="store_true",
+                    help="config 3: the GAT_edge variant (SURVEY 8(d): inputs after compute_relative_pos -- objects 303-d, rooms 3-d, "
+                         "edge_attr [E, 3] -- conv_block='GAT_edge'); reported separately from the config-3 line")
+    ap.add_argument("--real-fixture", action="store_true",
+                    help="config 2: the reference's real scene graph (tests/golden/dsg_x8F5xyUWy9e.json through the DSG reader: 5 rooms, "
+                         "62 objects, 356 + 2 + 62 + 62 directed edges; 300-d semantic block from a seeded per-label table) "
+                         "replicated x batch instead of the synthetic generator (SURVEY 8(d) config 2, second input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -98,12 +105,21 @@ def make_workload(args, rank):
     if args.config == 2:
         kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, conv_block="GraphSAGE", hidden_dim=64,
                   num_layers=3, dropout=0.25)
+        if args.real_fixture:
+            return kw, "HeterogeneousNetwork", workloads.real_fixture_batch(args.batch), "rooms", (
+                f"BASELINE configs[1], second input (SURVEY 8(d)): the reference's real MP3D scene graph x8F5xyUWy9e (5 rooms, 62 objects, "
+                f"482 directed edges) replicated x{args.batch}, 3-layer HeteroConv(SAGE) hidden 64, dropout 0.25")
         return kw, "HeterogeneousNetwork", workloads.config2_batch(args.batch, rank=rank), "rooms", (
             "BASELINE configs[1]: MP3D-like HeteroData (objects 306-d, rooms 6-d, 4 edge types), 3-layer HeteroConv(SAGE) "
             "hidden 64, dropout 0.25")
     if args.config == 3:
         kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, conv_block="GAT", GAT_hidden_dims=[128, 128],
                   GAT_heads=[4, 4, 4], GAT_concats=[True, True, False], dropout=0.25)
+        if args.gat_edge:
+            kw.update(input_dim_dict={"objects": 303, "rooms": 3}, conv_block="GAT_edge")
+            return kw, "HeterogeneousNetwork", workloads.config3_batch(args.batch, rank=rank, edge=True), "rooms", (
+                "BASELINE configs[2], GAT_edge variant (SURVEY 8(d)): inputs after compute_relative_pos (objects 303-d, rooms 3-d, "
+                "edge_attr [E, 3]), 3-layer HeteroConv(GAT_edge, 4 heads) hidden 128, dropout 0.25")
         return kw, "HeterogeneousNetwork", workloads.config3_batch(args.batch, rank=rank), "rooms", (
             "BASELINE configs[2]: MP3D-like HeteroData, 3-layer HeteroConv(GAT, 4 heads) hidden 128, dropout 0.25")
     if args.config == 4:
@@ -289,18 +305,39 @@ def launch_ranks(args) -> int:
         env.setdefault("OMP_NUM_THREADS", "4")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # exact PID of a child this process started
-            p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
+    # rank 0's stdout is drained by a thread so that the parent can WATCH all children: the first one that exits non-zero (a
+    # peer that died before or during the rendezvous would otherwise leave the others waiting out the store timeout, and the
+    # driver's SCALE run with them) ends the run -- the others get `fail_grace_s` to notice, then are killed (exact PIDs of
+    # children this process started; nothing is re-executed)
+    import threading
+
+    chunks = []
+    drain = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    drain.start()
+    fail_grace_s = float(os.environ.get("HMP_BENCH_FAIL_GRACE_S", "10"))
+    rc, failed_at = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at, rc = time.time(), bad[0]
+            print(f"bench.py: rank {codes.index(bad[0])} exited with code {bad[0]}; stopping the other ranks", file=sys.stderr)
+        if all(c is not None for c in codes):
+            break
+        if failed_at is not None and time.time() - failed_at > fail_grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    drain.join(timeout=5.0)
+    for p in procs:
+        rc = rc or (p.returncode or 0)
+    if rc == 0:
+        sys.stdout.write(b"".join(c for c in chunks if c).decode())
+        sys.stdout.flush()
     return rc
 
 
@@ -310,6 +347,11 @@ def rehearse_cpu(args, rank, world):
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    die = os.environ.get("HMP_BENCH_TEST_DIE_RANK")  # tests/test_bench_launcher.py: a rank that dies AFTER the rendezvous
+    if die is not None:
+        dist.barrier()
+        if int(die) == rank:
+            os._exit(3)
     buf = torch.zeros(126568 + 2)
     for _ in range(args.warmup):
         dist.all_reduce(buf)
@@ -392,6 +434,12 @@ def main():
             if float(ok.item()) == 0.0 and comm is not None:
                 comm.close()
                 comm = None
+    rccl_ranks = None
+    if comm is not None:
+        rccl_ranks, rccl_rank = comm.query()
+        assert rccl_ranks == max(world, 1) and rccl_rank == rank, (rccl_ranks, rccl_rank, world, rank)
+    elif world > 1 and args.dist_backend == "nccl":
+        rccl_ranks = dist.get_world_size()  # torch's ProcessGroupNCCL (RCCL) carries the collective
     step = net.train_step(lr=0.002, weight_decay=0.001, ignored_label=25, seed=20250225, use_graph=args.graph,
                           process_group=True if ((world > 1 or args.force_collective) and comm is None) else None,
                           force_collective=args.force_collective, comm=comm)
@@ -470,6 +518,9 @@ def main():
             "nodes_per_rank": dict(zip(nat.node_types, step._holder.n_nodes if step._holder else [])),
             "edges_per_rank": int(sum(step._holder.n_edges)) if step._holder else None,
             "parallelism": f"dp{world}",
+            "rank": rank,
+            # what RCCL itself reports for the communicator the gradient all-reduce ran on (ncclCommCount); None: no RCCL communicator
+            "rccl_ranks": rccl_ranks,
             "collective": (None if (world == 1 and not args.force_collective) else
                            ("ncclAllReduce enqueued by libhydra_mp on the executor's stream (hmp_comm_*)" if comm is not None else
                             f"torch.distributed all_reduce ({args.dist_backend})")),
@@ -604,22 +655,19 @@ def main():
             out["roofline_all"] = table
             # HBM traffic of the dominant family from the committed PMC passes of this same command (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_summary.py)
-            import glob
+            # (tools/pmc_families.py: exact kernel names per family, the file of THIS batch size, bytes of the family per step --
+            # a launch scope may cover several kernels -- divided by the family's scopes per step)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_families
 
-            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_cfg{args.config}.json")))
-            if pmc:
-                key = {"front": "front_kernel", "gemm_fwd": "gemm_", "gemm_bwd": "gemm_tn_direct_kernel" if fused else "gemm_",
-                       "agg_fwd": "agg_proj_fwd_kernel" if fused else "agg_fwd_", "agg_bwd": "agg_bwd_dx_kernel" if fused else "agg_bwd_",
-                       "gat_fwd": "gat_fwd_kernel", "gat_bwd": "gat_bwd", "grad_reduce": "grad_reduce_kernel"}[dom]
-                kern = json.load(open(pmc[-1]))["kernels"]
-                ks = [v for k, v in kern.items() if key in k]
-                # a launch scope of the family may cover several kernels (config 5: sliding-window kernel + plain kernel): bytes
-                # of the whole family per step (steps of the counter run = dispatches of the once-per-step un-pack kernel),
-                # divided by the scopes per step
-                steps_pmc = max([v["dispatches"] for k, v in kern.items() if "grad_reduce_kernel" in k] or [0])
-                if ks and steps_pmc and d["scopes_per_step"]:
-                    out["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in ks) / steps_pmc / d["scopes_per_step"])
-                    out["roofline"]["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
+            tag = "_gat_edge" if (args.config == 3 and args.gat_edge) else ("_real_fixture" if (args.config == 2 and args.real_fixture) else "")
+            pmc = pmc_families.pick_pmc_file(os.path.join(ROOT, "profiles"), args.config, args.batch, DEFAULT_BATCH[args.config], tag)
+            if pmc and not (args.config == 5 and args.big_objects != 1_000_000):
+                kern = json.load(open(pmc))["kernels"]
+                tr = pmc_families.family_traffic(kern, dom, d["scopes_per_step"])
+                if tr is not None:
+                    out["roofline"]["traffic"] = tr
+                    out["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
 
     # ---- CPU baseline: the oracle (op-for-op PyG restatement) on the host cores, bounded sample -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (the contract): other ranks would idle at the barrier

@@ -23,6 +23,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   bool tried = false;
   char why[256] = {0};
 };
@@ -50,6 +52,8 @@ RcclApi& api() {
   HMP_SYM(AllReduce, "ncclAllReduce")
   HMP_SYM(Broadcast, "ncclBroadcast")
   HMP_SYM(GetErrorString, "ncclGetErrorString")
+  HMP_SYM(CommCount, "ncclCommCount")
+  HMP_SYM(CommUserRank, "ncclCommUserRank")
 #undef HMP_SYM
   return a;
 }
@@ -100,6 +104,16 @@ extern "C" void hmp_comm_destroy(hmp_comm* c) {
   if (!c) return;
   if (c->comm && api().handle) (void)api().CommDestroy(c->comm);
   delete c;
+}
+
+extern "C" int hmp_comm_query(hmp_comm* c, int32_t* n_ranks, int32_t* rank) {
+  HMP_CHECK_ARG(c && c->comm && n_ranks && rank, "hmp_comm_query: bad argument");
+  int cnt = 0, rk = 0;
+  HMP_RCCL(api().CommCount(c->comm, &cnt));
+  HMP_RCCL(api().CommUserRank(c->comm, &rk));
+  *n_ranks = cnt;
+  *rank = rk;
+  return HMP_OK;
 }
 
 extern "C" int hmp_comm_allreduce_sum_f32(hmp_comm* c, float* d_buf, int64_t n, void* stream) {

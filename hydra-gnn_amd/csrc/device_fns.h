@@ -61,8 +61,12 @@ __device__ __forceinline__ void pack_item(const PackSeg& S, int item, const floa
 // One pack block (256 threads): one wavefront per item; `blk` indexes the SegBlocks table (4 items per block).
 // Block 0 also starts the step: it bumps the device step counter that dropout and Adam read later in the same step.
 __device__ __forceinline__ void pack_block(const PackSeg* __restrict__ segs, const SegBlocks& sb, const float* __restrict__ params,
-                                           float* __restrict__ packed, int* step_ctr, int blk) {
-  if (step_ctr && blk == 0 && threadIdx.x == 0) *step_ctr += 1;
+                                           float* __restrict__ packed, int* step_ctr, int* step_mirror, int blk) {
+  if (step_ctr && blk == 0 && threadIdx.x == 0) {
+    const int t = *step_ctr + 1;
+    *step_ctr = t;
+    if (step_mirror) *step_mirror = t;
+  }
   int si = 0;
   while (si + 1 < sb.n && blk >= sb.start[si + 1]) ++si;  // wave-uniform scan of the kernarg table
   const PackSeg S = segs[si];

@@ -240,7 +240,11 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
   }
   // pack role: 16 items per block; the block -> (segment, first item) map is a static device table
   const int kb = blk - a.gemm_blocks - a.plan_blocks;
-  if (a.step_ctr && kb == 0 && threadIdx.x == 0) *a.step_ctr += 1;
+  if (a.step_ctr && kb == 0 && threadIdx.x == 0) {
+    const int t = *a.step_ctr + 1;
+    *a.step_ctr = t;
+    if (a.step_mirror) *a.step_mirror = t;
+  }
   const int2 m = a.pack_map[kb];
   pack_item(a.segs[m.x], m.y + (int)(threadIdx.x >> 6), a.params, a.packed);
 }

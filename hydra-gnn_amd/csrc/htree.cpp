@@ -16,6 +16,7 @@
 // (trees, complete graphs, chordal graphs in general position) the result is the reference's up to the numbering of the clique
 // nodes; for all inputs it is a valid hierarchy of tree decompositions with the same structure rules.
 #include <algorithm>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <map>

@@ -88,6 +88,7 @@ struct FrontArgs {
   const int2* pack_map;  // per pack block: {segment, first item}; 16 items (packed row, 64-column chunk) per block
   float* packed;
   int* step_ctr;         // non-null: the pack role's first block bumps this device step counter
+  int* step_mirror;      // ... and leaves the new value here (NetState::last_step: the net never keeps the caller's pointer)
   int prob_start[FR_MAX_PROB];  // prob[i].blk_start again, next to the header fields (front_launch fills it): see karg_warm (common.h)
   int part_start[2 * HMP_MAX_EDGE_TYPES + 1];
   int rows_per_part[2 * HMP_MAX_EDGE_TYPES];
@@ -307,7 +308,8 @@ struct SegBlocks {
   int start[SEG_MAX + 1];
 };
 // step_ctr != null: block 0 increments *step_ctr (the fused step starts with the pack)
-int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, int* step_ctr, hipStream_t st);
+int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, int* step_ctr, int* step_mirror,
+                hipStream_t st);
 
 // A parameter gradient element (r, c) is the sum of up to 3 terms read from split-K slabs S (summed over slabs):
 //  GT_COPY       S[(r/C*Cp + r%C) * ld + c]                         (rows of the stacked operand; C = Cp: identity)
@@ -438,6 +440,7 @@ struct NetState {  // device resident
                    // an optimiser that keeps Adam moments passes its own counter (hmp_train_args::d_step)
   int status;      // bit 0: edge endpoint out of range, bit 1: label out of range
   float loss_sum, count;
+  int last_step;   // value of the counter the last started step ran on (its optimiser's, or `step`): what hmp_net_read_state reports
 };
 int masked_ce_launch(const float* logits, int ldl, int n_rows, int n_classes, const int64_t* labels, int64_t ignored,
                      float* grad, int ldg, float* out2, NetState* state_or_null, hipStream_t st);

@@ -844,6 +844,9 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
   // GAT layers: the projection's operand is the pack's OUTPUT (att . W rows), so only plan and pack share the launch (the plan,
   // 19 us at config 3, runs behind the 46 us pack); the link pass (t_pos) follows as its own launch
   const bool proj = Y.kind == HMP_CONV_SAGE && !n->any_gat;
+  // HMP_BRANCH bit 0 forks a side stream for pack + layer-0 projection BEFORE this launch: a front launch on the main stream that
+  // holds the pack (GAT: the projection's operand) would race with the projection on the side stream -> separate launches there
+  if (!proj && n->use_branches && (n->branch_mask & 1)) return false;
   memset(&fa, 0, sizeof(fa));
   // ---- projection problems
   for (int s = 0; s < n->T && proj; ++s) {
@@ -910,6 +913,7 @@ bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArg
   fa.pack_blocks = n->n_pack_blocks16;
   fa.packed = n->d_packed;
   fa.step_ctr = n->step_dev ? n->d_step : nullptr;
+  fa.step_mirror = &n->d_state->last_step;
   return true;
 }
 
@@ -1066,7 +1070,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     }
   } else {
     Scope sc(n, KC_PACK, side);
-    HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_step : nullptr, side));
+    HMP_TRY(pack_launch(n->d_pack_segs, n->pack_sb, d_params, n->d_packed, n->step_dev ? n->d_step : nullptr, &n->d_state->last_step, side));
   }
   bool z_done = false;
   for (int l = 0; l < n->L; ++l) {
@@ -1762,6 +1766,8 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
   n->fin_loss = true;
   const int rb = backward_impl(n, n->d_gout, n->out_ld, d_grads, d_params, nullptr, st);
   if (rb != HMP_OK) { n->chain_try = false; n->deferred.clear(); }
+  n->d_step = &n->d_state->step;  // the optimiser's counter belongs to the caller: not kept beyond this call
+  n->step_dev = false;
   return rb;
 }
 
@@ -1800,9 +1806,9 @@ extern "C" int hmp_net_read_state(hmp_net* n, int32_t* step, int32_t* status, vo
   NetState h;
   HMP_HIP(hipStreamSynchronize((hipStream_t)stream));
   HMP_HIP(hipMemcpy(&h, n->d_state, sizeof(h), hipMemcpyDeviceToHost));
-  if (n->d_step && n->d_step != &n->d_state->step)  // the last step counted on its optimiser's counter
-    HMP_HIP(hipMemcpy(&h.step, n->d_step, sizeof(int), hipMemcpyDeviceToHost));
-  if (step) *step = h.step;
+  // the counter of the last step (its optimiser's, hmp_train_args::d_step, or the net's own) was mirrored into the net's state by
+  // the kernel that bumped it: the caller's pointer is not kept beyond the call that passed it
+  if (step) *step = h.last_step;
   if (status) *status = h.status;
   return HMP_OK;
 }

@@ -176,13 +176,14 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(DropCfg cfg, int n_ro
 // it bumps the device step counter that dropout and Adam read later in the same step.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_kernel(const PackSeg* __restrict__ segs, const SegBlocks sb, const float* __restrict__ params,
-                                                   float* __restrict__ packed, int* step_ctr) {
-  pack_block(segs, sb, params, packed, step_ctr, (int)blockIdx.x);
+                                                   float* __restrict__ packed, int* step_ctr, int* step_mirror) {
+  pack_block(segs, sb, params, packed, step_ctr, step_mirror, (int)blockIdx.x);
 }
 
-int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, int* step_ctr, hipStream_t st) {
+int pack_launch(const PackSeg* d_segs, const SegBlocks& sb, const float* d_params, float* d_packed, int* step_ctr, int* step_mirror,
+                hipStream_t st) {
   if (sb.n == 0 || sb.start[sb.n] == 0) return HMP_OK;
-  hipLaunchKernelGGL(pack_kernel, dim3(sb.start[sb.n]), dim3(256), 0, st, d_segs, sb, d_params, d_packed, step_ctr);
+  hipLaunchKernelGGL(pack_kernel, dim3(sb.start[sb.n]), dim3(256), 0, st, d_segs, sb, d_params, d_packed, step_ctr, step_mirror);
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }

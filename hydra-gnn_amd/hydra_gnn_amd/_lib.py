@@ -170,9 +170,12 @@ SIGNATURES = {
     "hmp_comm_unique_id": (C.c_int, [_VP]),
     "hmp_comm_create": (C.c_int, [_VP, _I32, _I32, C.POINTER(_VP)]),
     "hmp_comm_destroy": (None, [_VP]),
+    "hmp_comm_query": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
     "hmp_comm_allreduce_sum_f32": (C.c_int, [_VP, _VP, _I64, _VP]),
     "hmp_comm_broadcast_f32": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
 }
+
+ABI_VERSION = 3  # the HMP_ABI_VERSION of include/hydra_mp.h this binding was written against (tests/test_abi.py compares them)
 
 _lib: Optional[C.CDLL] = None
 
@@ -201,8 +204,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.hmp_abi_version() != 2:
-        raise HydraMPError(f"ABI version mismatch: library {lib.hmp_abi_version()}, binding 2")
+    if lib.hmp_abi_version() != ABI_VERSION:
+        raise HydraMPError(f"ABI version mismatch: library {lib.hmp_abi_version()}, binding {ABI_VERSION} (stale build? run make)")
     for i, st in enumerate(_STRUCTS):
         if lib.hmp_sizeof(i) != C.sizeof(st):
             raise HydraMPError(f"struct layout mismatch for {st.__name__}: C {lib.hmp_sizeof(i)} vs ctypes {C.sizeof(st)}")

@@ -88,7 +88,13 @@ class _Store:
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        object.__getattribute__(self, "_d")[name] = value
+        d = object.__getattribute__(self, "_d")
+        if name == "edge_index":
+            # `ptr` / `ptr_version` describe the edge_index they were computed for (collate): a new edge_index drops them, so the
+            # engine never vouches for a graph-sorted edge list that was replaced after collation
+            d.pop("ptr", None)
+            d.pop("ptr_version", None)
+        d[name] = value
         object.__setattr__(self, "_v", object.__getattribute__(self, "_v") + 1)
 
     def __delattr__(self, name):
@@ -111,6 +117,13 @@ class _Store:
         out = _Store()
         for k, v in self.items():
             setattr(out, k, fn(v) if isinstance(v, torch.Tensor) else v)
+        if "ptr_version" in out and "edge_index" in out:  # the copy starts its own version history
+            stale = "edge_index" in self and int(self.edge_index._version) != int(self.ptr_version)
+            if stale:
+                delattr(out, "ptr")
+                delattr(out, "ptr_version")
+            else:
+                out.ptr_version = int(out.edge_index._version)
         return out
 
 
@@ -270,6 +283,7 @@ def collate(graphs: Sequence[HeteroData]) -> HeteroData:
         for q in parts:
             eoff.append(eoff[-1] + q.size(1))
         out[et].ptr = torch.tensor(eoff, dtype=torch.int64)
+        out[et].ptr_version = int(out[et].edge_index._version)  # an in-place edit of edge_index afterwards invalidates `ptr`
         if "edge_attr" in graphs[0][et]:
             out[et].edge_attr = torch.cat([g[et].edge_attr for g in graphs], dim=0)
     # host knowledge of the collation: lets the engine run the per-graph phases of a training step as one launch (hmp_batch)

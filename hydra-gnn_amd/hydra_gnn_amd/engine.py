@@ -97,7 +97,8 @@ class NativeNet:
         self._lib = None
         self._fwd_token = 0
         self._compute_bf16 = False
-        self._plan_key = None  # identity of the edge lists whose plan the workspace holds (predict() reuses it across frames)
+        self._plan_key = None  # versions of the edge lists whose plan the workspace holds (predict() reuses it across frames)
+        self._plan_tensors = None  # ... and the edge tensors themselves (identity is the test; holding them pins their addresses)
 
     def set_compute(self, precision: str) -> None:
         """'fp32' (default): every projection on the exact fp32 MFMA path.  'bf16': GEMM calls in the throughput-bound regime
@@ -334,6 +335,11 @@ class NativeNet:
             for i, e in enumerate(self.edge_types):
                 st_ = data[e] if e in data.edge_types else None
                 p = getattr(st_, "ptr", None) if st_ is not None else None
+                # `ptr` vouches for ONE edge_index (data.collate stamps its version): an edge list edited in place since then is
+                # described without it (any edge order accepted; a replaced edge_index dropped `ptr` already)
+                pv = getattr(st_, "ptr_version", None) if st_ is not None else None
+                if pv is not None and int(h.edge_tensors[i]._version) != int(pv):
+                    p = None
                 if p is not None and p.is_cuda and p.dtype == torch.int64 and p.is_contiguous() and p.numel() == ng + 1:
                     h.keep.append(p)
                     h.c.d_edge_ptr[i] = p.data_ptr()
@@ -401,11 +407,18 @@ class NativeNet:
             st = _lib.stream_ptr()
             # consecutive frames with the SAME edge tensors (unchanged in place): the plan of the previous call is reused
             # (bin/room_classification_server:273-299 re-infers on a graph whose topology did not change)
-            key = None if h.converted else (id(self._ws), tuple(h.n_nodes), tuple((t.data_ptr(), t._version, t.size(-1)) for t in h.edge_tensors))
-            h.c.plan_valid = 1 if (key is not None and key == self._plan_key) else 0
+            # "same" = the very same tensor OBJECTS as the previous call (kept alive in `_plan_tensors`, so the allocator cannot
+            # hand their addresses to a new frame's edge lists) at the same `_version`: a fresh tensor that merely lands on a
+            # recycled address rebuilds the plan
+            key = None if h.converted else (id(self._ws), tuple(h.n_nodes), tuple(t._version for t in h.edge_tensors))
+            prev = self._plan_tensors
+            same = (key is not None and key == self._plan_key and prev is not None and len(prev) == len(h.edge_tensors)
+                    and all(a is b for a, b in zip(prev, h.edge_tensors)))
+            h.c.plan_valid = 1 if same else 0
             _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), flat.data_ptr(), 0, 0, 0, C.byref(out_p), C.byref(ld), st))
             self._fwd_token += 1
             self._plan_key = key
+            self._plan_tensors = list(h.edge_tensors) if key is not None else None
             if n > 0:
                 _lib.check(self._lib.hmp_argmax_rows(out_p.value, ld.value, n, int(n_classes), self._pred_dev.data_ptr(), st))
                 self._pred_host[:n].copy_(self._pred_dev[:n], non_blocking=True)
@@ -418,7 +431,7 @@ class NativeNet:
         _lib.check(self._lib.hmp_net_forward(self._handle, C.byref(h.c), self._flat.data_ptr(), int(training), seed, rng_step,
                                              C.byref(out_p), C.byref(ld), _lib.stream_ptr()))
         self._fwd_token += 1
-        self._plan_key = None
+        self._plan_key = self._plan_tensors = None
         out = self._ws_view(out_p.value, int(h.c.n_out), ld.value).clone()
         if self.aux_readout is None:
             return out
@@ -450,6 +463,17 @@ class NativeNet:
         off = p.value - self._ws.data_ptr()
         raw = self._ws[off:off + rows.value * ld.value * esz].view(torch.bfloat16 if b16.value else torch.float32)
         return raw.view(rows.value, ld.value)[:, :width.value].to(torch.float32).clone()
+
+    STATUS_BITS = {1: "an edge endpoint is out of range (the edge was dropped)", 2: "a label is out of range",
+                   4: "an edge lies outside the rows of the graph its Batch.ptr slice belongs to (stale or wrong edge `ptr`)"}
+
+    def check_status(self) -> None:
+        """Raise if a kernel flagged bad input data since the net was created (sticky device status word; synchronises).  The
+        training loop reads the loss every step (``base_training_job.py:216``), which is where :meth:`TrainStep.loss` calls this."""
+        _, status = self.read_state()
+        if status:
+            what = "; ".join(msg for bit, msg in self.STATUS_BITS.items() if status & bit) or "unknown bit"
+            raise _lib.HydraMPError(f"device status word = {status}: {what}")
 
     def read_state(self) -> Tuple[int, int]:
         step, status = C.c_int32(), C.c_int32()
@@ -596,7 +620,7 @@ class TrainStep:
         with torch.cuda.device(dev):
             net._ensure_workspace(h, dev)
             net._fwd_token += 1  # the step overwrites the activations of any earlier forward()
-            net._plan_key = None
+            net._plan_key = net._plan_tensors = None
             if not self.use_graph:
                 st = _lib.stream_ptr()
                 if self._world() == 1 and not self.force_collective:
@@ -669,7 +693,7 @@ class TrainStep:
         if self.use_graph:
             raise _lib.HydraMPError("TrainStep.run steps a NEW batch every call: create the step with use_graph=False")
         net._fwd_token += 1
-        net._plan_key = None
+        net._plan_key = net._plan_tensors = None
         self._batch_key = None
         self._holder = holder
         st = _lib.stream_ptr()
@@ -695,4 +719,5 @@ class TrainStep:
     def loss(self) -> float:
         """mean CE over the valid labels of the last step (global when data parallel); synchronises."""
         t = self.grads[self.net.n_active: self.net.n_active + 2].tolist()
+        self.net.check_status()
         return t[0] / max(t[1], 1.0)

@@ -110,6 +110,16 @@ class NativeComm:
             _lib.check(lib.hmp_comm_create(ids, rank, world, C.byref(h)))
         return cls(h, rank, world)
 
+    def query(self):
+        """(rank count, rank) as RCCL reports them for this communicator (ncclCommCount / ncclCommUserRank)."""
+        import ctypes as C
+
+        from . import _lib
+
+        cnt, rk = C.c_int32(), C.c_int32()
+        _lib.check(_lib.load().hmp_comm_query(self._h, C.byref(cnt), C.byref(rk)))
+        return cnt.value, rk.value
+
     def all_reduce_sum_(self, buf: torch.Tensor, n: int) -> None:
         """sum ``buf[:n]`` (fp32, device) over the ranks, in place, on torch's CURRENT stream."""
         from . import _lib

@@ -220,3 +220,30 @@ def htree_batch(batch_size: int = 128, seed: int = BASE_SEED + 4, fixture: Optio
     rng = np.random.Generator(np.random.PCG64(seed))
     n = int(npz["n_graphs"])
     return collate([htree_graph(npz, i % n, rng) for i in range(batch_size)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 2, second input: the reference's real scene graph replicated x B
+# ---------------------------------------------------------------------------------------------------------------------
+DSG_FIXTURE = os.path.join(os.path.dirname(HTREE_FIXTURE), "dsg_x8F5xyUWy9e.json")
+
+
+def real_fixture_frame(fixture: Optional[str] = None, seed: int = BASE_SEED) -> HeteroData:
+    """The reference's test scene graph (``tests/test_data/x8F5xyUWy9e_0_gt_partial_dsg_1447.json``, static layers committed as
+    ``tests/golden/dsg_x8F5xyUWy9e.json``) through the engine's own reader with the training thresholds
+    (``prepare_hydra_mp3d_training.py:24-26``): 5 rooms, 62 objects, 356 + 2 + 62 + 62 directed edges.  The 300-d semantic block
+    is a seeded per-label table (word2vec is a download); room labels are drawn (the bench needs a loss, not these labels).
+    Object connectivity runs on the device (``csrc/dsg.hip``): needs the GPU."""
+    from . import dsg
+
+    rog = dsg.RoomObjectGraph(dsg.load_dsg_json(fixture or DSG_FIXTURE))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    table = rng.normal(0.0, 0.15, size=(int(rog.sg.label[rog.objects].max()) + 1, 300))
+    oo = dsg.object_connectivity(rog, 1.5, 2.0, 0.2)
+    frame = dsg.to_hetero_data(rog, oo, {"objects": table[rog.sg.label[rog.objects]]}).to("cpu")
+    frame["rooms"].y = torch.from_numpy(rng.integers(0, NUM_ROOM_LABELS, size=len(rog.rooms)))
+    return frame
+
+
+def real_fixture_batch(batch_size: int = 32, fixture: Optional[str] = None) -> HeteroData:
+    return collate([real_fixture_frame(fixture)] * batch_size)

@@ -24,8 +24,9 @@
 extern "C" {
 #endif
 
-/* 2: round 2 -- hmp_batch grew (plan_valid, d_node_ptr, n_graphs, max_graph_nodes, d_edge_ptr), hmp_train_args::d_step; sections 10-12 */
-#define HMP_ABI_VERSION 2
+/* 2: round 2 -- hmp_batch grew (plan_valid, d_node_ptr, n_graphs, max_graph_nodes, d_edge_ptr), hmp_train_args::d_step; sections 10-12
+ * 3: round 3 -- hmp_comm_query; hmp_net_read_state reports the counter of the last step from the net's own state */
+#define HMP_ABI_VERSION 3
 
 #define HMP_OK 0
 #define HMP_E_ARG 1      /* bad argument (shape / alignment / capacity) */
@@ -298,8 +299,11 @@ int hmp_net_step_fused(hmp_net* net, const hmp_batch* batch, float* d_params, fl
 int hmp_net_hidden(hmp_net* net, int32_t layer, int32_t node_type, const void** d_h, int32_t* ld, int32_t* n_rows,
                    int32_t* width, int32_t* is_bf16);
 /* compute mode of the dense projections: 0 (default) exact fp32 MFMA everywhere; 1 = GEMM calls in the throughput-bound regime
- * (>= 1024 64x64 output tiles: BASELINE config 5) round their fp32 operands to bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation.  Storage stays fp32.  Not within the 1e-5 parity bar: an explicit precision choice of the caller. */
+ * (>= 1024 64x64 output tiles: BASELINE config 5, "hidden=256 bf16") round their operands to bf16 and run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; in that regime the intermediates that are only ever gathered or fed to those
+ * GEMMs (projected rows Z, their gradient dZ, hidden activations H, input gradients G of 256-wide layers) are also STORED as bf16
+ * -- features, logits, parameters, gradients and optimiser state stay fp32.  Not within the 1e-5 parity bar: an explicit
+ * precision choice of the caller, checked against oracle/bf16_emul.py (tests/test_gpu_config5.py). */
 int hmp_net_set_compute(hmp_net* net, int32_t bf16);
 /* host copy of {step counter, status bits}; synchronises the stream */
 int hmp_net_read_state(hmp_net* net, int32_t* step, int32_t* status, void* stream);
@@ -423,6 +427,8 @@ typedef struct hmp_comm hmp_comm; /* opaque */
 int hmp_comm_unique_id(void* id128);
 int hmp_comm_create(const void* id128, int32_t rank, int32_t world, hmp_comm** out);
 void hmp_comm_destroy(hmp_comm* comm);
+/* what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): the rank count a benchmark line may quote */
+int hmp_comm_query(hmp_comm* comm, int32_t* n_ranks, int32_t* rank);
 int hmp_comm_allreduce_sum_f32(hmp_comm* comm, float* d_buf, int64_t n, void* stream);
 int hmp_comm_broadcast_f32(hmp_comm* comm, float* d_buf, int64_t n, int32_t root, void* stream);
 

@@ -23,7 +23,25 @@ def declared_functions():
 def test_library_exists_and_loads_without_gpu():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.hmp_abi_version() == 2
+    assert lib.hmp_abi_version() == header_abi_version() == _lib.ABI_VERSION
+
+
+def header_abi_version():
+    return int(re.search(r"^#define\s+HMP_ABI_VERSION\s+(\d+)", open(HEADER).read(), re.M).group(1))
+
+
+def test_build_entry_point_runs_and_agrees_with_the_header():
+    """`__graft_entry__.build()` carried a hard-coded ABI number and raised at HEAD.  The driver's build check is this
+    call: make (a no-op when the library is current), dlopen, bind every symbol, compare the ABI number with the header."""
+    import importlib
+    import sys
+
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    assert ge._header_abi_version() == header_abi_version()
+    text = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert not re.search(r"hmp_abi_version\(\)\s*==\s*\d", text), "no literal ABI number in the entry point"
+    ge.build()
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -51,3 +51,19 @@ def test_a_failing_rank_fails_the_launcher():
     p = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=300)
     assert p.returncode != 0
     assert p.stdout.strip() == ""
+
+
+def test_a_rank_that_dies_after_the_rendezvous_ends_the_run_quickly():
+    """the parent used to block on rank 0, which waits for its dead peer until the store / collective timeout.  Now
+    the parent watches every child: rank 1 exits (code 3) after the rendezvous barrier, rank 0 sits in an all-reduce that can never
+    complete; the launcher must stop it and return non-zero well within 30 s, with no JSON line."""
+    import time
+
+    t0 = time.time()
+    p = run(["--gpus", "2", "--rehearse-cpu", "--steps", "5", "--warmup", "2"],
+            env_extra={"HMP_BENCH_TEST_DIE_RANK": "1", "HMP_BENCH_FAIL_GRACE_S": "3"}, timeout=120)
+    took = time.time() - t0
+    assert p.returncode != 0, p.stdout
+    assert p.stdout.strip() == ""
+    assert "rank 1 exited with code 3" in p.stderr or "exited with code" in p.stderr, p.stderr[-1500:]
+    assert took < 30.0, f"launcher needed {took:.1f} s to give up"

@@ -217,3 +217,25 @@ def test_collate_records_where_each_graph_starts():
     assert b.max_graph_nodes == max(max(g[t].num_nodes for t in g.node_types) for g in gs)
     del b[EDGE_TYPES[0]].ptr  # a caller that permutes an edge list drops the statement
     assert "ptr" not in b[EDGE_TYPES[0]]
+
+
+def test_edge_offsets_follow_the_edge_index_they_were_computed_for():
+    """collate() attaches per-graph edge offsets (`ptr`) that let the plan build read slices; they describe ONE edge_index.
+    Replacing edge_index drops them; an in-place edit leaves a version stamp that no longer matches (the engine then describes the
+    batch without `ptr`), and `.to()` does not carry a stale `ptr` over."""
+    from hydra_gnn_amd import workloads
+    from hydra_gnn_amd.data import collate
+
+    rng = np.random.Generator(np.random.PCG64(3))
+    batch = collate([workloads.mp3d_like_graph(rng) for _ in range(3)])
+    et = ("objects", "objects_to_objects", "objects")
+    assert "ptr" in batch[et] and batch[et].ptr_version == batch[et].edge_index._version
+    moved = batch.to("cpu")
+    assert "ptr" in moved[et] and moved[et].ptr_version == moved[et].edge_index._version
+    # in-place edit: the stamp no longer matches; a copy made now carries no offsets
+    batch[et].edge_index[0, 0] = batch[et].edge_index[0, 1]
+    assert batch[et].ptr_version != batch[et].edge_index._version
+    assert "ptr" not in batch.to("cpu")[et]
+    # replacement: offsets dropped at once
+    batch[et].edge_index = batch[et].edge_index[:, :-2].contiguous()
+    assert "ptr" not in batch[et] and "ptr_version" not in batch[et]

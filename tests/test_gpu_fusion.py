@@ -605,7 +605,10 @@ def test_edge_offsets_that_do_not_match_the_edge_order_are_flagged():
     batch = workloads.config2_batch(6)
     et = ("objects", "objects_to_objects", "objects")
     perm = torch.randperm(batch[et].edge_index.size(1), generator=torch.Generator().manual_seed(1))
+    vouch = batch[et].ptr
     batch[et].edge_index = batch[et].edge_index[:, perm].contiguous()
+    assert "ptr" not in batch[et], "a replaced edge_index must drop the offsets computed for the old one"
+    batch[et].ptr = vouch  # a caller that (wrongly) vouches for the new list by hand
     with fuse_env("1"):
         _, net = build(SAGE_KW, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
         net.eval()

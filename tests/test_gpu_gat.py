@@ -217,9 +217,38 @@ def make_gat_replay(net, batch):
 def test_gat_training_mode_parity_with_replayed_masks(block, hidden, heads, concats):
     """Training mode as train_mp3d.py runs it (dropout 0.25 on the attention coefficients AND on the ELU outputs): the oracle
     replays the engine's Philox keep-masks; logits, loss and every gradient at 1e-5.  (models/utils.py:31-87)"""
+    training_mode_parity(block, hidden, heads, concats, workloads.mp3d_like_batch(6, seed=29, relative_pos=(block == "GAT_edge")))
+
+
+@pytest.mark.parametrize("block", ["GAT", "GAT_edge"])
+def test_gat_training_mode_parity_at_the_bench_size(block):
+    """the same check on the batch `bench.py --config 3 [--gat-edge]` times (B = 64, ~4 k objects, ~27 k edges, 4 heads x
+    128): the 128x128-tile projections, the split weight gradients and the multi-round gat_* launches that 6 graphs never reach."""
+    batch = workloads.config3_batch(64, edge=(block == "GAT_edge"))
+    assert batch["objects"].x.size(0) > 3000
+    training_mode_parity(block, [128, 128], [4, 4, 4], [True, True, False], batch)
+
+
+def test_gat_with_side_stream_branches_orders_pack_before_the_projection(monkeypatch):
+    """HMP_BRANCH=1 forks a side stream for pack + layer-0 projection; a GAT front launch (plan + pack on the main
+    stream) must not run next to it.  Same results as the single-stream sequence, bit for bit."""
+    batch = workloads.config3_batch(6)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HMP_BRANCH", mode)
+        _, net = gat_pair("GAT", [16, 16], [2, 2, 2], [True, True, False], seed=3)
+        net.eval()
+        gb = batch.to(DEV)
+        outs = [net(gb).detach().clone() for _ in range(4)]
+        assert all(torch.equal(o, outs[0]) for o in outs)
+        res[mode] = outs[0]
+    monkeypatch.delenv("HMP_BRANCH")
+    assert torch.equal(res["0"], res["1"])
+
+
+def training_mode_parity(block, hidden, heads, concats, batch):
     p = 0.25
     ora, net = gat_pair(block, hidden, heads, concats, dropout=p)
-    batch = workloads.mp3d_like_batch(6, seed=29, relative_pos=(block == "GAT_edge"))
     net.train()
     pred = net(batch.to(DEV))
     replay = make_gat_replay(net, batch)

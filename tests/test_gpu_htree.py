@@ -254,3 +254,41 @@ def test_natively_built_htrees_drive_the_model():
     pred = net(batch.to(DEV))
     assert pred.shape == (batch["room_virtual"].x.size(0), 26)
     compare(net, o64, pred, pred_ref, batch["room_virtual"].y)
+
+
+def test_htree_training_mode_parity_at_the_bench_size():
+    """what `bench.py --config 4` times -- 16 H-tree graphs per rank, hidden 128, 4 SAGE layers, LeafPool, dropout 0.25 in
+    TRAINING mode -- against the float64 oracle with the engine's keep-masks replayed (hmp_dropout_mask): logits, loss (masked CE)
+    and every gradient at 1e-5.  At this size the launches take the tile shapes the 7-graph eval test never reaches
+    (`agg_proj_fwd_kernel<32>` at three workgroups per CU, several rounds of tiles).  Then the fused native step (plan + fwd + CE in
+    the pool path + bwd + Adam) against the oracle's loss with the masks of THAT step."""
+    from hydra_gnn_amd import _lib
+
+    torch.manual_seed(4)
+    kw = dict(input_dim_dict=HT_DIMS, output_dim=26, conv_block="GraphSAGE", hidden_dim=128, num_layers=4,
+              disable_initialization=True, dropout=0.25)
+    ora = omodels.HeterogeneousNeuralTreeNetwork(**kw)
+    net = HeterogeneousNeuralTreeNetwork(**kw)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net = net.to(DEV).train()
+    batch = workloads.htree_batch(16, seed=workloads.BASE_SEED + 4)  # the bench's rank-0 batch
+    lib = _lib.require_device()
+
+    def replay(x, pp, training, tag):
+        if not training or pp == 0:
+            return x
+        layer, t = tag[1:].split(".", 1)
+        n, F = x.shape
+        m = torch.zeros(max(n * F, 1), dtype=torch.uint8, device=DEV)
+        if n * F:
+            _lib.check(lib.hmp_dropout_mask(net._seed, net._rng_step, net._drop_stream(int(layer), t), pp, n, F, m.data_ptr(), _lib.stream_ptr()))
+        return x * m[: n * F].view(n, F).cpu().to(x.dtype) / (1.0 - pp)
+
+    pred = net(batch.to(DEV))
+    ora.dropout_fn = replay
+    o64 = copy.deepcopy(ora).double().train()
+    pred_ref = o64(to64(batch))
+    assert pred.shape == (batch["room_virtual"].num_nodes, 26) and pred.shape[0] > 60
+    compare(net, o64, pred, pred_ref, batch["room_virtual"].y)
+    net.eval()
+    assert not torch.allclose(net(batch.to(DEV)), pred, atol=1e-3), "the masks did not act"

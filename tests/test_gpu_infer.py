@@ -115,3 +115,31 @@ def test_predict_reuses_the_plan_across_frames_with_unchanged_topology():
     assert net.native()._plan_key is None
     ref.load_state_dict(net.state_dict())
     assert torch.equal(net.predict(frame), ref.predict(collate([frame.to("cpu")]).to(DEV)))
+
+
+def test_predict_rebuilds_the_plan_when_a_new_frame_lands_on_recycled_addresses():
+    """the server builds fresh edge tensors per frame; once frame k is freed the caching allocator hands frame k+1 the
+    same addresses (same shape, `_version` 0).  Reuse is decided by tensor IDENTITY (the previous frame's edge tensors are kept
+    alive by the net), so the changed connectivity is seen: the answer equals a full rebuild on a fresh net."""
+    torch.manual_seed(5)
+    kw = dict(input_dim_dict={"objects": 306, "rooms": 6}, output_dim=26, conv_block="GraphSAGE", hidden_dim=64, num_layers=3, dropout=0.25)
+    net = HeterogeneousNetwork(**kw).to(DEV).eval()
+    ref = HeterogeneousNetwork(**kw).to(DEV).eval()
+    ref.load_state_dict(net.state_dict())
+    host = collate([workloads.mp3d_like_graph(np.random.default_rng(21))])
+    et_or = ("objects", "objects_to_rooms", "rooms")
+    et_ro = ("rooms", "rooms_to_objects", "objects")
+    n_rooms = int(host["rooms"].x.size(0))
+    assert n_rooms >= 2
+    frame = host.to(DEV)
+    ptrs = {e: frame[e].edge_index.data_ptr() for e in frame.edge_types}
+    net.predict(frame)
+    del frame
+    # frame k+1: every object re-assigned to the next room (same counts, same shapes, different connectivity)
+    host[et_or].edge_index = torch.stack([host[et_or].edge_index[0], (host[et_or].edge_index[1] + 1) % n_rooms])
+    host[et_ro].edge_index = host[et_or].edge_index.flip([0])
+    frame2 = host.to(DEV)
+    recycled = sum(frame2[e].edge_index.data_ptr() == ptrs[e] for e in frame2.edge_types)
+    got = net.predict(frame2).clone()
+    want = ref.predict(host.to(DEV)).clone()
+    assert torch.equal(got, want), f"stale plan used ({recycled} edge tensors on recycled addresses)"

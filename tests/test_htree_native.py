@@ -128,6 +128,7 @@ def test_loopy_inputs_satisfy_the_construction_rules(name):
     check_rules(scene, ref)  # the rules are the reference's own: its output satisfies them too
     same = signature(t) == signature(ref)
     print(f"{name}: native {t['counts']} reference {ref['counts']} identical labelled tree: {same}")
+    assert same, f"{name}: the native construction no longer returns the reference's labelled H-tree (a regression: it did in round 2)"
     # the leaf SET is tie-independent (every object of a room, every room)
     assert set(t["object_orig"].tolist()) == set(ref["object_orig"].tolist())
     assert set(t["room_orig"].tolist()) == set(ref["room_orig"].tolist())
