@@ -266,6 +266,18 @@ __global__ __launch_bounds__(256, (MI * NI > 1) ? 2 : 3) void gemm_kernel(const 
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_t[i][j][r] = 0.f;
+  if (P.Cadd && kw == 0 && z == 0) {  // block-uniform per K group: the product accumulates ON TOP of the addend (GemmProblem::Cadd)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 32 * MI + 32 * i + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+          const int col = n0 + wn * 32 * NI + 32 * j + (lane & 31);
+          acc_t[i][j][r] = (row < P.M && col < P.N) ? P.Cadd[(int64_t)row * P.ldadd + col] : 0.f;
+        }
+  }
   f32x16& acc = acc_t[0][0];
 
   TileRegs<BM, BK> ra;

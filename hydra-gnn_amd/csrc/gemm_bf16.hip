@@ -286,6 +286,18 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void gemm_bf16_kernel(const 
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (P.Cadd && z == 0) {  // block-uniform: the product accumulates ON TOP of the addend (GemmProblem::Cadd)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (MI * 32) + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+          const int col = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
+          acc[i][j][r] = (row < P.M && col < P.N) ? P.Cadd[(int64_t)row * P.ldadd + col] : 0.f;
+        }
+  }
 
   f32x16 acc1[ONES ? MI : 1];
 #pragma unroll
@@ -702,6 +714,33 @@ static int ws_launch(const GemmProblem& p, hipStream_t st) {
 // form (the 256 x 256 bf16 weight tile fits LDS).
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_bf16: %d problems", gb.n);
+  {  // backward products of the 10^6-node regime: operand-stationary kernels (gemm_bf16_bwd.hip), one launch per problem
+    GemmBatch rest;
+    memset(&rest, 0, sizeof(rest));
+    int where[GEMM_MAX_PROB];
+    int taken = 0;
+    for (int i = 0; i < gb.n; ++i) {
+      if (gemm_bf16_dx_takes(gb.p[i], want_split)) {
+        HMP_TRY(gemm_bf16_dx_launch(gb.p[i], st));
+        gb.p[i].ksplit = 1;
+        ++taken;
+      } else if (gemm_bf16_dw_takes(gb.p[i], want_split)) {
+        int ns = 1;
+        HMP_TRY(gemm_bf16_dw_launch(gb.p[i], max_slabs, &ns, st));
+        gb.p[i].ksplit = ns;
+        ++taken;
+      } else {
+        where[rest.n] = i;
+        rest.p[rest.n++] = gb.p[i];
+      }
+    }
+    if (taken) {
+      if (rest.n == 0) return HMP_OK;
+      HMP_TRY(gemm_bf16_launch(rest, want_split, max_slabs, st));  // (no problem of `rest` is taken here again)
+      for (int i = 0; i < rest.n; ++i) gb.p[where[i]].ksplit = rest.p[i].ksplit;
+      return HMP_OK;
+    }
+  }
   {  // tall NT products over a bf16 A: the weight-stationary kernel, one launch per problem; the rest stays with the tiled kernel
     GemmBatch rest;
     memset(&rest, 0, sizeof(rest));

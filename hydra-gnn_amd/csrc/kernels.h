@@ -34,8 +34,21 @@ struct GemmProblem {
   int epi, act;
   int drop_on;
   DropCfg drop;          // dropout site of H (quad index = row*(ldh/4) + col/4)
+  // NN form only: gather-add before the mask -- C[m, :] += sum over the entries k in [g_rowptr[m], g_rowptr[m+1]) of
+  // g_rows[g_col[k], 0:N] * g_deg[g_col[k]]: the gradient of an AGGREGATE-FIRST conv's segment mean (net.hip), whose source
+  // rows are this problem's output rows; g_rows is fp32 [.][g_ld].  g_rowptr == null: none
+  // (gemm_bf16_dx_kernel only; the tiled kernels take the same term as a materialised matrix:)
+  const int* g_rowptr;
+  const int* g_col;
+  const float* g_deg;
+  const float* g_rows;
+  int g_ld;
+  const float* Cadd;     // NN form: fp32 [M][ldadd] added to the product before the mask (null: none)
+  int ldadd;
 };
 
+// sum over the CSC entries of `row` of g_rows[g_col[k], col] * g_deg[g_col[k]] (row < 0: nothing) -- the tiled kernels' form of
+// GemmProblem::g_rowptr (one element at a time: the regime that uses it in earnest runs gemm_bf16_dx_kernel)
 constexpr int GEMM_MAX_PROB = 8;
 constexpr int GEMM_TALL_SLABS = 192;  // split-K slabs the tall weight-gradient kernel may ask for (== net.hip: MAX_SLABS, the slab buffer's size)
 struct GemmBatch {
@@ -48,6 +61,11 @@ struct GemmBatch {
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
 // same contract on the bf16 matrix pipe (operands rounded to bf16 on their way into LDS, fp32 accumulate): gemm_bf16.hip
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
+// operand-stationary backward kernels of the 10^6-node regime (gemm_bf16_bwd.hip); *_takes: the problem fits the kernel's limits
+bool gemm_bf16_dx_takes(const GemmProblem& p, bool want_split);
+int gemm_bf16_dx_launch(const GemmProblem& p, hipStream_t st);
+bool gemm_bf16_dw_takes(const GemmProblem& p, bool want_split);
+int gemm_bf16_dw_launch(const GemmProblem& p, int max_slabs, int* n_slabs, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // front kernel of the small-batch step (front.hip): layer-0 projection tiles + plan parts + pack blocks in one launch
@@ -263,6 +281,13 @@ struct TAggArgs {
 int agg_bwd_launch(TAggArgs& a, hipStream_t st);
 // same + the row-local input-gradient GEMM per 16-row tile (requires every segment width <= 256, ncols <= 896)
 int agg_bwd_dx_launch(TAggArgs& a, hipStream_t st);
+
+// aggregate-first convs (aggfirst.hip): segment mean of source rows (fp32 or bf16) into fp32 rows, and its transpose with the
+// activation / dropout mask of the source rows for source types that have no input-gradient GEMM in the layer
+int seg_mean_rows_launch(const void* x, int ldx, int x_bf16, int F, const int* rowptr, const int* col, int n_rows, float* m, int ldm,
+                         hipStream_t st);
+int seg_mean_rows_t_launch(const float* dm, int lddm, int F, const int* t_rowptr, const int* t_col, const float* degf, int n_rows,
+                           const void* h, int ldh, int h_bf16, int act, int drop_on, float dscale, void* g, int ldg, int g_bf16, hipStream_t st);
 
 // graph-local chain (aggregate.hip: chain_kernel): all launches between the front kernel and the weight-gradient GEMM as phases
 // of ONE launch, one workgroup per graph.  The argument block lives in device memory (several KB).

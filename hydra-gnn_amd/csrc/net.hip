@@ -35,6 +35,12 @@ struct ConvLayout {
   bool wd_is_src;         // GAT: the destination role uses lin_src's weights
   // per-conv workspace (GAT)
   float *smax, *sden, *alpha_drop, *dlogit, *dlogit_orig;
+  // SAGE, aggregate-first (hmp_conv_spec::agg_first): M = segment mean of the SOURCE rows [n_dst][ld_m] (fp32), projected by
+  // W_l [f_out][ldw(src)] at wc_off into columns [aoff, aoff + f_out) of Z[l][dst]; dM its gradient; weight-gradient slabs at cslab_off
+  bool agg_first;
+  int aoff, ld_m;
+  int64_t wc_off, cslab_off;
+  float *mrows, *dmrows;
 };
 
 struct LayerLayout {
@@ -43,6 +49,8 @@ struct LayerLayout {
   int live[HMP_MAX_CONVS];            // indices of live convs
   ConvLayout conv[HMP_MAX_CONVS];
   int n_in[HMP_MAX_NODE_TYPES];       // live convs reaching the node type
+  bool reads[HMP_MAX_NODE_TYPES];     // the layer reads this node type's state (ncols > 0, or the source of an aggregate-first conv)
+  int aggf_of_src[HMP_MAX_NODE_TYPES];  // the aggregate-first conv whose SOURCE is this node type, -1: none
   int ncols[HMP_MAX_NODE_TYPES];      // width of Z[l][s] (0: type is not read by this layer)
   int roff[HMP_MAX_NODE_TYPES];       // SAGE root segment column in Z[l][t], -1 if none
   int64_t wp_off[HMP_MAX_NODE_TYPES]; // packed weights [ncols][ldw]
@@ -96,6 +104,12 @@ struct hmp_net {
   int* t_ell[HMP_MAX_EDGE_TYPES];   // the single-launch plan build only: valid while ell_ok
   bool ell_ok = false;
   bool ell_on = false;              // this call: HMP_ELL=1
+  bool any_agg_first = false;       // some conv is evaluated aggregate-first (large batches only: never with the small-batch sequence)
+  int* d_iota = nullptr;            // 0, 1, 2, ..: row extents AND ids of the identity lists that hand an aggregate-first block to
+  float* d_ones = nullptr;          // the aggregation kernels (in-degree 1, weight 1)
+  float* d_sadd = nullptr;          // fallback of the gather-add epilogue: the source rows' gradient term as an fp32 matrix (GemmProblem::Cadd)
+  int iota_cap = 0;
+  int64_t sadd_floats = 0;
   float* d_row_lv = nullptr;        // per output row {loss, valid} of the fused step's loss kernel
   bool fin_loss = false;            // the next gradient un-pack also finalises {loss_sum, count}
 
@@ -209,6 +223,8 @@ int build_layout(hmp_net* n) {
       Y.ncols[t] = 0;
       Y.roff[t] = -1;
       Y.n_in[t] = 0;
+      Y.reads[t] = false;
+      Y.aggf_of_src[t] = -1;
     }
     Y.n_live = 0;
     int n_outgoing[HMP_MAX_NODE_TYPES] = {0};
@@ -229,15 +245,27 @@ int build_layout(hmp_net* n) {
         HMP_CHECK_ARG(!(C.edge_dim > 0 && C.fill_mean && C.self_loops), "net: fill_value='mean' with edge attributes is not supported (the reference passes zeros)");
         HMP_CHECK_ARG(!C.self_loops || C.src == C.dst, "net: self loops need src == dst (the reference sets add_self_loops = (src == dst))");
       }
+      HMP_CHECK_ARG(!C.agg_first || (Y.kind == HMP_CONV_SAGE && C.src != C.dst), "net: agg_first is for SAGE convs between two node types");
       if (!C.active) continue;
       Y.live[Y.n_live++] = c;
       ++Y.n_in[C.dst];
-      ++n_outgoing[C.src];
-      HMP_CHECK_ARG(Y.n_in[C.dst] <= AGG_MAX_IN && n_outgoing[C.src] <= AGG_MAX_IN, "net: more than %d convs share a node type", AGG_MAX_IN);
+      const bool aggf = C.agg_first != 0;
+      ++n_outgoing[aggf ? C.dst : C.src];  // an aggregate-first block is gathered (identity lists) from the DESTINATION type's own Z
+      HMP_CHECK_ARG(Y.n_in[C.dst] <= AGG_MAX_IN && n_outgoing[C.src] <= AGG_MAX_IN && n_outgoing[C.dst] <= AGG_MAX_IN,
+                    "net: more than %d convs share a node type", AGG_MAX_IN);
+      Y.reads[C.src] = Y.reads[C.dst] = true;
       if (Y.kind == HMP_CONV_SAGE) {
         HMP_CHECK_ARG(C.w0 >= 0 && C.b0 >= 0 && C.w1 >= 0, "net: SAGE conv needs lin_l.weight, lin_l.bias, lin_r.weight");
-        Q.coff = Y.ncols[C.src];
-        Y.ncols[C.src] += fpad(C.f_out);
+        if (aggf) {
+          HMP_CHECK_ARG(Y.aggf_of_src[C.src] < 0, "net: layer %d has two aggregate-first convs from node type %d (at most one)", l, C.src);
+          Y.aggf_of_src[C.src] = c;
+          Q.agg_first = true;
+          Q.ld_m = fpad(n->dim[l][C.src]);
+          n->any_agg_first = true;
+        } else {
+          Q.coff = Y.ncols[C.src];
+          Y.ncols[C.src] += fpad(C.f_out);
+        }
       } else {
         HMP_CHECK_ARG(C.w0 >= 0 && C.a0 >= 0 && C.a1 >= 0 && C.b0 >= 0, "net: GAT conv needs lin_src, att_src, att_dst, bias");
         HMP_CHECK_ARG(C.edge_dim == 0 || (C.w2 >= 0 && C.a2 >= 0), "net: GAT_edge conv needs lin_edge, att_edge");
@@ -253,6 +281,15 @@ int build_layout(hmp_net* n) {
     }
     HMP_CHECK_ARG(Y.n_live > 0, "net: layer %d has no live conv", l);
     if (Y.kind == HMP_CONV_SAGE) {
+      // column order of Z[l][t]: [blocks of the convs sourced from t] [aggregate-first blocks of convs that END in t] [root]:
+      // the root block stays last, where the backward GEMMs can take it from the output gradient in place
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        const hmp_conv_spec& C = Ls.convs[c];
+        if (!Y.conv[c].agg_first) continue;
+        Y.conv[c].aoff = Y.ncols[C.dst];
+        Y.ncols[C.dst] += fpad(C.f_out);
+      }
       for (int t = 0; t < n->T; ++t)
         if (Y.n_in[t] > 0) {
           Y.roff[t] = Y.ncols[t];
@@ -278,6 +315,15 @@ int build_layout(hmp_net* n) {
       Y.bslab_off[t] = slabs;
       if (Y.kind == HMP_CONV_GAT && Y.n_in[t] > 0) slabs += (int64_t)MAX_SLABS * fpad(Ls.out_dim[t]) * 4;
     }
+    for (int i = 0; i < Y.n_live; ++i) {  // aggregate-first convs: their W_l packed on its own, their weight-gradient slabs
+      const int c = Y.live[i];
+      if (!Y.conv[c].agg_first) continue;
+      const hmp_conv_spec& C = Ls.convs[c];
+      Y.conv[c].wc_off = packed;
+      packed += (int64_t)fpad(C.f_out) * Y.ldw[C.src];
+      Y.conv[c].cslab_off = slabs;
+      slabs += (int64_t)MAX_SLABS * fpad(C.f_out) * Y.lddw[C.src];
+    }
     if (Y.kind == HMP_CONV_GAT) {
       for (int i = 0; i < Y.n_live; ++i) {
         const int c = Y.live[i];
@@ -299,7 +345,7 @@ int build_layout(hmp_net* n) {
         HMP_CHECK_ARG(C.dst == S.readout_type || C.dst == S.aux_readout_type,
                       "net: last-layer conv %d is active but does not feed a readout type", Y.live[i]);
       else
-        HMP_CHECK_ARG(n->lay[l + 1].ncols[C.dst] > 0, "net: layer %d conv %d is active but layer %d never reads its output", l, Y.live[i], l + 1);
+        HMP_CHECK_ARG(n->lay[l + 1].reads[C.dst], "net: layer %d conv %d is active but layer %d never reads its output", l, Y.live[i], l + 1);
     }
   }
   n->packed_floats = packed;
@@ -354,14 +400,15 @@ int build_tables(hmp_net* n) {
       memset(&s, 0, sizeof(s));
       if (Y.kind == HMP_CONV_SAGE) {
         s.kind = PACK_SUM;
-        s.dst = Y.wp_off[C.src] + (int64_t)Q.coff * Y.ldw[C.src];
+        s.dst = Q.agg_first ? Q.wc_off : Y.wp_off[C.src] + (int64_t)Q.coff * Y.ldw[C.src];
         s.rows = C.f_out; s.rows_pad = fpad(C.f_out); s.cols = fs; s.ld_dst = Y.ldw[C.src]; s.ld_src = fs;
         s.nsrc = 1; s.src[0] = C.w0;
         push_pack(s);
         GradSeg g;
         memset(&g, 0, sizeof(g));
         g.dst = C.w0; g.rows = C.f_out; g.cols = fs; g.n_terms = 1;
-        g.t[0] = term(GT_COPY, slab_id_w(l, C.src), Y.slab_off[C.src] + (int64_t)Q.coff * Y.lddw[C.src], Y.lddw[C.src], C.f_out, C.f_out);
+        if (Q.agg_first) g.t[0] = term(GT_COPY, slab_id_v(l, c), Q.cslab_off, Y.lddw[C.src], C.f_out, C.f_out);
+        else g.t[0] = term(GT_COPY, slab_id_w(l, C.src), Y.slab_off[C.src] + (int64_t)Q.coff * Y.lddw[C.src], Y.lddw[C.src], C.f_out, C.f_out);
         push_grad(g);
         continue;
       }
@@ -502,6 +549,7 @@ int build_tables(hmp_net* n) {
 // workspace carving: returns bytes; when base != null also assigns pointers ---------------------------
 size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
   size_t off = 0;
+  n->sadd_floats = 0;
   auto take = [&](size_t bytes) -> char* {
     char* p = base ? base + off : nullptr;
     off += align256(bytes);
@@ -541,6 +589,17 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
         n->dZ[l][t] = (float*)take((size_t)cn[t] * Y.ncols[t] * 4);
       }
     }
+    int64_t sf = 0;  // gather-add scratch: one matrix per aggregate-first conv of the layer, side by side
+    for (int i = 0; i < Y.n_live; ++i) {
+      const int c = Y.live[i];
+      ConvLayout& Q = Y.conv[c];
+      if (!Q.agg_first) continue;
+      const hmp_conv_spec& C = S.layers[l].convs[c];
+      Q.mrows = (float*)take((size_t)cn[C.dst] * Q.ld_m * 4);
+      Q.dmrows = (float*)take((size_t)cn[C.dst] * Q.ld_m * 4);
+      sf += (int64_t)cn[C.src] * Q.ld_m;
+    }
+    n->sadd_floats = sf > n->sadd_floats ? sf : n->sadd_floats;
     if (Y.kind != HMP_CONV_GAT) continue;
     for (int i = 0; i < Y.n_live; ++i) {
       const int c = Y.live[i];
@@ -560,6 +619,15 @@ size_t carve(hmp_net* n, char* base, const int32_t* cn, const int64_t* ce) {
   n->d_out = (float*)take((size_t)cap_out * n->out_ld * 4);
   n->d_gout = (float*)take((size_t)cap_out * n->out_ld * 4);
   n->d_row_lv = (float*)take((size_t)cap_out * 2 * 4);
+  n->d_iota = nullptr; n->d_ones = nullptr; n->d_sadd = nullptr;
+  if (n->any_agg_first) {
+    int mx = 1;
+    for (int t = 0; t < n->T; ++t) mx = cn[t] > mx ? cn[t] : mx;
+    n->iota_cap = mx;
+    n->d_iota = (int*)take((size_t)(mx + 1) * 4);
+    n->d_ones = (float*)take((size_t)mx * 4);
+    n->d_sadd = (float*)take((size_t)n->sadd_floats * 4);
+  }
   return off;
 }
 
@@ -770,6 +838,7 @@ int run_plan(hmp_net* n, const hmp_batch* b, hipStream_t st) {
 // forward pass, the input gradient in the backward pass) runs inside the aggregation kernel on 16-row tiles.  Large
 // batches keep the stand-alone 64x64-tile GEMM (16-row tiles would re-read the weights from L2 once per 16 rows).
 inline bool fuse_small(const hmp_net* n, const hmp_batch* b) {
+  if (n->any_agg_first) return false;  // aggregate-first convs exist in the stand-alone launch sequence only (a large-batch choice)
   if (n->fuse_mode >= 0) return n->fuse_mode == 1;
   int64_t total = 0;
   for (int t = 0; t < n->T; ++t) total += b->n_nodes[t];
@@ -1078,6 +1147,10 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
     LayerLayout& Y = n->lay[l];
     st = (l == 0) ? side : main_st;
     bool z16 = false;  // this layer's projected rows are stored as bf16 (decided with the projection, read by the aggregation)
+    if (l == 0 && !front && n->any_agg_first) {  // the segment means of layer 0 read the plan: build it first (no side stream here)
+      if (!n->reuse_plan) HMP_TRY(run_plan(n, b, main_st));
+      if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
+    }
     if (l == 0 && front && fa.n_prob > 0) {
       // projection, plan and pack already ran in the front kernel
     } else if (!z_done) {  // grouped projection (skipped when the previous layer's aggregation kernel already produced Z[l])
@@ -1117,9 +1190,42 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
       }
       HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
     }
+    if (n->any_agg_first && !z_done) {
+      // aggregate-first convs: mean of the SOURCE rows per destination row, then the destination-sized projection into the conv's
+      // block of Z[l][dst] -- a second launch: the main one wrote that block too (zero weights there)
+      std::vector<GemmProblem> pa;
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        const ConvLayout& Q = Y.conv[c];
+        if (!Q.agg_first) continue;
+        const hmp_conv_spec& C = Ls.convs[c];
+        if (b->n_nodes[C.dst] == 0 || b->n_nodes[C.src] == 0 || b->n_edges[C.edge_type] == 0) continue;
+        {
+          Scope sa(n, KC_AGG_FWD, st);
+          const hmp_plan& Pl = n->plan[C.edge_type];
+          HMP_TRY(seg_mean_rows_launch(h_ptr(n, l, C.src), h_ld(n, l, C.src), n->h16[l][C.src] ? 1 : 0, n->dim[l][C.src], Pl.d_rowptr, Pl.d_col,
+                                       b->n_nodes[C.dst], Q.mrows, Q.ld_m, st));
+        }
+        GemmProblem p;
+        memset(&p, 0, sizeof(p));
+        p.A = Q.mrows; p.lda = Q.ld_m; p.trans_a = 0;
+        p.B = n->d_packed + Q.wc_off; p.ldb = Y.ldw[C.src]; p.trans_b = 1;
+        p.C = z16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(n->Z[l][C.dst]) + Q.aoff) : n->Z[l][C.dst] + Q.aoff;
+        p.c_bf16 = z16 ? 1 : 0;
+        p.ldc = Y.ncols[C.dst];
+        p.M = b->n_nodes[C.dst]; p.N = fpad(C.f_out); p.K = n->dim[l][C.src];
+        p.n_real = p.N;
+        p.epi = EPI_NONE;
+        pa.push_back(p);
+      }
+      if (!pa.empty()) {
+        Scope sg(n, KC_GEMM_FWD, st);
+        HMP_TRY(gemm_many(pa, false, st, nullptr, n->compute_bf16 != 0));
+      }
+    }
     z_done = false;
     if (l == 0 && !front) {
-      if (!n->reuse_plan) HMP_TRY(run_plan(n, b, main_st));
+      if (!n->reuse_plan && !n->any_agg_first) HMP_TRY(run_plan(n, b, main_st));
       if (side != main_st) HMP_TRY(fork_to(n, side, main_st));  // join
       st = main_st;
     }
@@ -1160,6 +1266,12 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           if (C.dst != t) continue;
           if (b->n_nodes[C.src] == 0 || b->n_edges[C.edge_type] == 0) continue;
           AggIn& I = D.in[D.n_in++];
+          if (Y.conv[c].agg_first) {  // the conv's block of this type's own Z, through identity lists (in-degree 1)
+            I.rowptr = n->d_iota; I.col = n->d_iota;
+            I.z = n->Z[l][t]; I.ldz = Y.ncols[t]; I.coff = Y.conv[c].aoff;
+            I.same_type = 0; I.n_src = b->n_nodes[t]; I.ell = nullptr;
+            continue;
+          }
           I.rowptr = n->plan[C.edge_type].d_rowptr;
           I.col = n->plan[C.edge_type].d_col;
           I.z = n->Z[l][C.src]; I.ldz = Y.ncols[C.src]; I.coff = Y.conv[c].coff;
@@ -1213,6 +1325,14 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         if (hb) {
           double work = 0.0;
           for (int s = 0; s < n->T; ++s) work += (double)b->n_nodes[s] * n->lay[l + 1].ncols[s] * n->dim[l + 1][s];
+          // an aggregate-first conv of the next layer reads its source rows with the segment-mean kernels (both storage forms):
+          // counted as the projection it stands for, so that the choice does not depend on the order of evaluation
+          for (int i = 0; i < n->lay[l + 1].n_live; ++i) {
+            const int c = n->lay[l + 1].live[i];
+            if (!n->lay[l + 1].conv[c].agg_first) continue;
+            const hmp_conv_spec& C = S.layers[l + 1].convs[c];
+            work += (double)b->n_nodes[C.src] * fpad(C.f_out) * n->dim[l + 1][C.src];
+          }
           hb = work >= 1e9 || bf16_all();  // gemm_takes_bf16's work criterion
         }
         const char* hv = getenv("HMP_H16");  // 0: keep fp32 activations (tests)
@@ -1336,6 +1456,16 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         for (int i = 0; i < Y.n_live; ++i) {
           const int c = Y.live[i];
           const hmp_conv_spec& C = Ls.convs[c];
+          if (Y.conv[c].agg_first) {  // its block of dZ[l][dst] = the destination's own output gradient (identity lists, weight 1)
+            if (C.dst != s || b->n_nodes[C.src] == 0 || b->n_edges[C.edge_type] == 0) continue;
+            TAggOut& O = T.out[T.n_out++];
+            O.t_rowptr = n->d_iota; O.t_col = n->d_iota; O.rowptr = n->d_iota; O.degf = n->d_ones;
+            int ldg;
+            O.g = g_of(s, ldg);
+            O.ldg = ldg; O.coff = Y.conv[c].aoff; O.F = fpad(C.f_out);
+            O.same_type = 0; O.n_dst = b->n_nodes[s]; O.t_ell = nullptr;
+            continue;
+          }
           if (C.src != s) continue;
           TAggOut& O = T.out[T.n_out++];
           const hmp_plan& P = n->plan[C.edge_type];
@@ -1425,10 +1555,52 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
       HMP_TRY(fork_to(n, st, wst));
     }
     const bool need_dx = !dx_fused && ((l > 0) || (d_gx != nullptr));
+    // aggregate-first convs: dM = dZ_block * W_l (destination-sized), ahead of the launch whose epilogue scatters it
+    auto dz_at = [&](int t, int col) -> const float* {
+      return dz16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(n->dZ[l][t]) + col) : n->dZ[l][t] + col;
+    };
+    auto aggf_live = [&](int c) {
+      const hmp_conv_spec& C = Ls.convs[c];
+      return Y.conv[c].agg_first && b->n_nodes[C.dst] > 0 && b->n_nodes[C.src] > 0 && b->n_edges[C.edge_type] > 0;
+    };
+    if (need_dx && n->any_agg_first) {
+      std::vector<GemmProblem> pp;
+      for (int i = 0; i < Y.n_live; ++i) {
+        const int c = Y.live[i];
+        if (!aggf_live(c)) continue;
+        const hmp_conv_spec& C = Ls.convs[c];
+        float* want = l > 0 ? n->G[l][C.src] : d_gx[C.src];
+        if (!want) continue;
+        const ConvLayout& Q = Y.conv[c];
+        GemmProblem p;
+        memset(&p, 0, sizeof(p));
+        p.A = dz_at(C.dst, Q.aoff); p.lda = Y.ncols[C.dst]; p.trans_a = 0; p.a_bf16 = dz16 ? 1 : 0;
+        p.B = n->d_packed + Q.wc_off; p.ldb = Y.ldw[C.src]; p.trans_b = 0;
+        p.C = Q.dmrows; p.ldc = Q.ld_m;
+        p.M = b->n_nodes[C.dst]; p.N = n->dim[l][C.src]; p.K = fpad(C.f_out);
+        p.n_real = p.N;
+        p.epi = EPI_NONE;
+        pp.push_back(p);
+      }
+      if (!pp.empty()) {
+        HMP_TRY(chain_flush(n, st));
+        Scope sp(n, KC_GEMM_BWD, st);
+        HMP_TRY(gemm_many(pp, false, st, nullptr, n->compute_bf16 != 0));
+      }
+    }
+    // the gradient the source rows of aggregate-first conv c receive: the segment mean's transpose of dM
+    struct SrcTerm { int c; const hmp_plan* P; const float* degf; };
+    auto src_term = [&](int s, SrcTerm& T) -> bool {
+      const int c = Y.aggf_of_src[s];
+      if (c < 0 || !aggf_live(c)) return false;
+      T.c = c; T.P = &n->plan[Ls.convs[c].edge_type]; T.degf = n->degf[Ls.convs[c].edge_type];
+      return true;
+    };
     if (need_dx) {  // input gradient, masked by the previous layer's activation/dropout derivative
       HMP_TRY(chain_flush(n, st));
       Scope sc(n, KC_GEMM_BWD, st);
       std::vector<GemmProblem> ps;
+      std::vector<int> ps_type;
       for (int s = 0; s < n->T; ++s) {
         if (Y.ncols[s] == 0 || b->n_nodes[s] == 0) continue;
         float* dst = l > 0 ? n->G[l][s] : d_gx[s];
@@ -1452,10 +1624,18 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           if (p.act == HMP_ACT_NONE && !p.drop_on) p.epi = EPI_NONE;
         }
         ps.push_back(p);
+        ps_type.push_back(s);
       }
       // bf16 compute mode, 10^6-row regime: G[l] is only ever gathered by layer l-1's transposed aggregation -> stored as bf16
       // when this GEMM runs on the bf16 kernel and that aggregation takes its one-wavefront-per-row shape (see forward_impl)
-      if (l > 0 && !n->fuse_now && n->lay[l - 1].kind != HMP_CONV_GAT && gemm_takes_bf16(ps, n->compute_bf16 != 0)) {
+      // (a large source type whose gradient is the masked transpose alone -- no GEMM in this layer -- counts like the GEMM it replaces)
+      bool big_alone = false;
+      for (int s = 0; s < n->T; ++s) {
+        SrcTerm T;
+        if (Y.ncols[s] == 0 && b->n_nodes[s] >= 32768 && src_term(s, T)) big_alone = true;
+      }
+      if (l > 0 && !n->fuse_now && n->lay[l - 1].kind != HMP_CONV_GAT &&
+          (gemm_takes_bf16(ps, n->compute_bf16 != 0) || (n->compute_bf16 != 0 && big_alone))) {
         const hmp_layer_spec& Lp = S.layers[l - 1];
         int fmin = 1 << 30, fmax = 0;
         for (int t = 0; t < n->T; ++t) {
@@ -1473,7 +1653,55 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
           g16[l] = true;
         }
       }
-      HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
+      // source types of aggregate-first convs: + transpose of the segment mean, before the mask.  Fused into the epilogue of the
+      // weight-stationary kernel where that one runs the problem; else as an fp32 matrix the tiled kernels start their sums from
+      int64_t sadd_used = 0;
+      for (size_t i = 0; i < ps.size(); ++i) {
+        SrcTerm T;
+        if (!src_term(ps_type[i], T)) continue;
+        const ConvLayout& Q = Y.conv[T.c];
+        GemmProblem& p = ps[i];
+        p.g_rowptr = T.P->d_t_rowptr; p.g_col = T.P->d_t_col; p.g_deg = T.degf; p.g_rows = Q.dmrows; p.g_ld = Q.ld_m;
+        if (n->compute_bf16 != 0 && gemm_bf16_dx_takes(p, false)) continue;
+        p.g_rowptr = nullptr;
+        HMP_CHECK_ARG(sadd_used + (int64_t)p.M * Q.ld_m <= n->sadd_floats, "net: gather-add scratch too small");
+        float* sm = n->d_sadd + sadd_used;
+        sadd_used += (int64_t)p.M * Q.ld_m;
+        HMP_TRY(seg_mean_rows_t_launch(Q.dmrows, Q.ld_m, Q.ld_m, T.P->d_t_rowptr, T.P->d_t_col, T.degf, p.M, nullptr, 0, 0, 0, 0, 1.f, sm, Q.ld_m, 0, st));
+        p.Cadd = sm; p.ldadd = Q.ld_m;
+      }
+      if (!ps.empty()) HMP_TRY(gemm_many(ps, false, st, nullptr, n->compute_bf16 != 0));
+      // source types with NO stacked columns in this layer (their only live conv is the aggregate-first one): no GEMM -- the
+      // masked transpose directly
+      for (int s = 0; s < n->T; ++s) {
+        SrcTerm T;
+        if (Y.ncols[s] != 0 || b->n_nodes[s] == 0 || !src_term(s, T)) continue;
+        float* dst = l > 0 ? n->G[l][s] : d_gx[s];
+        if (!dst) continue;
+        const ConvLayout& Q = Y.conv[T.c];
+        const hmp_layer_spec* Lp = l > 0 ? &S.layers[l - 1] : nullptr;
+        const bool drop_on = Lp && n->training && Lp->dropout > 0.f;
+        const int act = Lp ? Lp->act : HMP_ACT_NONE;
+        const bool masked = Lp && (act != HMP_ACT_NONE || drop_on);
+        bool gb = false;
+        if (l > 0 && ps.empty()) {  // no GEMM decided the storage of G[l]: the same rule (see above)
+          const hmp_layer_spec& Lq = S.layers[l - 1];
+          int fmin = 1 << 30, fmax = 0;
+          for (int t = 0; t < n->T; ++t) {
+            if (n->lay[l - 1].roff[t] < 0 || b->n_nodes[t] == 0) continue;
+            const int f = fpad(Lq.out_dim[t]);
+            fmin = f < fmin ? f : fmin;
+            fmax = f > fmax ? f : fmax;
+          }
+          const char* zv = getenv("HMP_Z16");
+          g16[l] = n->compute_bf16 != 0 && !n->fuse_now && n->lay[l - 1].kind != HMP_CONV_GAT && fmax <= 256 && fmin > 128 &&
+                   (n->ld[l][s] & 3) == 0 && !(zv && zv[0] == '0') && (b->n_nodes[s] >= 32768 || bf16_all());
+        }
+        gb = l > 0 && g16[l];
+        HMP_TRY(seg_mean_rows_t_launch(Q.dmrows, Q.ld_m, fpad(n->dim[l][s]), T.P->d_t_rowptr, T.P->d_t_col, T.degf, b->n_nodes[s],
+                                       masked ? (const void*)n->H[l][s] : nullptr, n->ld[l][s], n->h16[l][s] ? 1 : 0, act, drop_on ? 1 : 0,
+                                       drop_on ? 1.f / (1.f - Lp->dropout) : 1.f, dst, l > 0 ? n->ld[l][s] : b->ldx[s], gb ? 1 : 0, st));
+      }
     }
     {  // weight + bias gradient: dWp = dZ^T * [H | 1], split over node chunks (+ GAT: bias column sums, d V_edge)
       std::vector<GemmProblem> local_ps;
@@ -1499,6 +1727,21 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         p.M = Y.ncols[s]; p.N = n->dim[l][s] + 1; p.K = b->n_nodes[s];
         p.n_real = n->dim[l][s]; p.aug_ones = 1;
         add(slab_id_w(l, s), p);
+      }
+      for (int i = 0; i < Y.n_live; ++i) {  // aggregate-first convs: dW_l = dZ_block^T * M (destination-sized)
+        const int c = Y.live[i];
+        if (!aggf_live(c)) continue;
+        const hmp_conv_spec& C = Ls.convs[c];
+        const ConvLayout& Q = Y.conv[c];
+        GemmProblem p;
+        memset(&p, 0, sizeof(p));
+        p.A = dz_at(C.dst, Q.aoff); p.lda = Y.ncols[C.dst]; p.trans_a = 1; p.a_bf16 = dz16 ? 1 : 0;
+        p.B = Q.mrows; p.ldb = Q.ld_m; p.trans_b = 0;
+        p.C = n->d_slabs + Q.cslab_off; p.ldc = Y.lddw[C.src];
+        p.slab_stride = (int64_t)fpad(C.f_out) * Y.lddw[C.src];
+        p.M = fpad(C.f_out); p.N = n->dim[l][C.src]; p.K = b->n_nodes[C.dst];
+        p.n_real = p.N; p.aug_ones = 0;
+        add(slab_id_v(l, c), p);
       }
       if (Y.kind == HMP_CONV_GAT) {
         for (int t = 0; t < n->T; ++t) {  // bias: column sums of the output gradient
@@ -1673,6 +1916,13 @@ extern "C" int hmp_net_bind_workspace(hmp_net* n, void* d_workspace, size_t byte
   // zero once: padding columns of every buffer stay zero for the lifetime of the binding
   HMP_HIP(hipMemset(d_workspace, 0, need));
   HMP_TRY(build_gat_tables(n));
+  if (n->any_agg_first) {  // identity lists of the aggregate-first blocks
+    std::vector<int> io((size_t)n->iota_cap + 1);
+    for (size_t i = 0; i < io.size(); ++i) io[i] = (int)i;
+    std::vector<float> on((size_t)n->iota_cap, 1.0f);
+    HMP_HIP(hipMemcpy(n->d_iota, io.data(), io.size() * sizeof(int), hipMemcpyHostToDevice));
+    HMP_HIP(hipMemcpy(n->d_ones, on.data(), on.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   n->bound = true;
   n->have_fwd = false;
   n->plan_ok = false;

@@ -42,7 +42,7 @@ class ConvSpec(C.Structure):
         ("kind", C.c_int32), ("edge_type", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32),
         ("f_out", C.c_int32), ("heads", C.c_int32), ("concat", C.c_int32), ("self_loops", C.c_int32),
         ("edge_dim", C.c_int32), ("fill_mean", C.c_int32), ("shared_lin", C.c_int32), ("active", C.c_int32),
-        ("att_dropout", C.c_float),
+        ("agg_first", C.c_int32), ("att_dropout", C.c_float),
         ("w0", C.c_int64), ("w1", C.c_int64), ("w2", C.c_int64), ("a0", C.c_int64), ("a1", C.c_int64),
         ("a2", C.c_int64), ("b0", C.c_int64),
     ]
@@ -167,6 +167,8 @@ SIGNATURES = {
     "hmp_htree_sizes": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I64)]),
     "hmp_htree_fill": (C.c_int, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(_VP)]),
     "hmp_htree_destroy": (None, [_VP]),
+    "hmp_gemm_bf16_dx": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _VP, _I32, _VP, _I32, _I32, _I32, _F32, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "hmp_gemm_bf16_dw": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _VP, _I32, _I32, _VP, _I32, _I64, _I32, C.POINTER(_I32), _I32, _I32, _I32, _VP]),
     "hmp_comm_unique_id": (C.c_int, [_VP]),
     "hmp_comm_create": (C.c_int, [_VP, _I32, _I32, C.POINTER(_VP)]),
     "hmp_comm_destroy": (None, [_VP]),

@@ -16,6 +16,7 @@ torch is used for device memory, streams and ``torch.distributed`` only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -99,6 +100,7 @@ class NativeNet:
         self._compute_bf16 = False
         self._plan_key = None  # versions of the edge lists whose plan the workspace holds (predict() reuses it across frames)
         self._plan_tensors = None  # ... and the edge tensors themselves (identity is the test; holding them pins their addresses)
+        self._agg_first: Dict[Tuple[int, int], bool] = {}  # (layer, conv) -> evaluated aggregate-first (decided with the first batch)
 
     def set_compute(self, precision: str) -> None:
         """'fp32' (default): every projection on the exact fp32 MFMA path.  'bf16': GEMM calls in the throughput-bound regime
@@ -199,15 +201,43 @@ class NativeNet:
                 cs.fill_mean = int(conv.gat.get("fill_mean", 0))
                 cs.shared_lin = int(conv.gat.get("shared_lin", 0))
                 cs.active = int(conv.active)
+                cs.agg_first = int(self._agg_first.get((l, c), False))
                 cs.att_dropout = float(conv.gat.get("dropout", 0.0) or 0.0)
                 for r in ("w0", "w1", "w2", "a0", "a1", "a2", "b0"):
                     p = conv.params.get(r)
                     setattr(cs, r, self.param_offsets[id(p)] if p is not None else -1)
         return sp
 
-    def _ensure_handle(self):
+    def _decide_agg_first(self, h: Optional["_BatchHolder"]) -> None:
+        """Which SAGE convs are evaluated in the reference's own order -- mean of the source rows, then ``lin_l`` on the (few)
+        destination rows ([PyG] SAGEConv) -- instead of projecting every source row first (both are exact).
+        Decided ONCE, from the sizes of the first batch the handle is built for (the choice is part of the executor's static
+        layout): a conv between two node types whose source type is large (>= 32 768 rows) and at least 16x the destination type,
+        with at most two edges per source row -- objects -> rooms at 10^6 objects; at most one per source type and layer.
+        ``HMP_AGG_FIRST=0`` never, ``=1`` every eligible conv whatever the sizes (tests)."""
+        self._agg_first = {}
+        mode = os.environ.get("HMP_AGG_FIRST")
+        if mode == "0" or (h is None and mode != "1"):
+            return
+        nt = {t: i for i, t in enumerate(self.node_types)}
+        et = {e: i for i, e in enumerate(self.edge_types)}
+        for l, layer in enumerate(self.layers):
+            taken = set()
+            for c, conv in enumerate(layer.convs):
+                s, _, t = conv.edge_type
+                if conv.kind != CONV_SAGE or not conv.active or s == t or s in taken:
+                    continue
+                if mode != "1":
+                    ns, nd, ne = h.n_nodes[nt[s]], h.n_nodes[nt[t]], h.n_edges[et[conv.edge_type]]
+                    if not (ns >= 32768 and ns >= 16 * max(nd, 1) and 0 < ne <= 2 * ns):
+                        continue
+                self._agg_first[(l, c)] = True
+                taken.add(s)
+
+    def _ensure_handle(self, h: Optional["_BatchHolder"] = None):
         if self._handle is None:
             self._lib = _lib.require_device()
+            self._decide_agg_first(h)
             h = C.c_void_p()
             sp = self._spec()
             _lib.check(self._lib.hmp_net_create(C.byref(sp), C.byref(h)))
@@ -355,7 +385,7 @@ class NativeNet:
         return h
 
     def _ensure_workspace(self, h: _BatchHolder, device) -> None:
-        handle = self._ensure_handle()
+        handle = self._ensure_handle(h)
         need_n, need_e = h.n_nodes, h.n_edges
         if self._caps is not None and self._ws is not None and self._ws.device == device:
             cn, ce = self._caps

@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 /* 2: round 2 -- hmp_batch grew (plan_valid, d_node_ptr, n_graphs, max_graph_nodes, d_edge_ptr), hmp_train_args::d_step; sections 10-12
- * 3: round 3 -- hmp_comm_query; hmp_net_read_state reports the counter of the last step from the net's own state */
+ * 3: round 3 -- hmp_comm_query; hmp_net_read_state reports the counter of the last step from the net's own state;
+ *    hmp_conv_spec::agg_first; hmp_gemm_bf16_dx / hmp_gemm_bf16_dw */
 #define HMP_ABI_VERSION 3
 
 #define HMP_OK 0
@@ -102,6 +103,23 @@ int hmp_gemm_bf16_a16(const uint16_t* d_a, int32_t lda, const float* d_w, int32_
                       int32_t M, int32_t N, int32_t K, void* stream);
 int hmp_gemm_f32(const float* d_a, int32_t lda, int32_t trans_a, const float* d_b, int32_t ldb, int32_t trans_b,
                  float* d_c, int32_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* The two backward products of that projection in the 10^6-node regime (csrc/gemm_bf16_bwd.hip; unit-test entries of what the
+ * executor calls; reference: autograd of F.linear inside [PyG] SAGEConv, models/utils.py:14).  dZ is bf16 [M][lddz]; its columns
+ * from `split` on may live in a second bf16 matrix d_dz2 [M][lddz2] (the root block of dZ is the output gradient itself; split = 0:
+ * one matrix; otherwise a multiple of 256).
+ *   dx: G[M, N] = mask . (dZ[M, K] * W[K, N]), W fp32 [K][ldw] rounded to bf16, fp32 accumulation, G written as bf16; mask from the
+ *       stored activations d_h (bf16 [M][ldh], NULL = none): act' of HMP_ACT_*, and with drop_on an element stored as -0 is a dropped
+ *       one (factor 0), kept ones are scaled by drop_scale.  Tall problems (M >= 32768, K in {256, 512, 768}, N % 128 == 0) run on
+ *       the weight-stationary kernel.
+ *   dw: slabs of dW[Mw, F + 1] = dZ[nodes, Mw]^T * [H | 1][nodes, F + 1]: slab z (fp32 [Mw][ldc] at d_slabs + z * slab_stride) holds
+ *       the sum over one node range, *n_slabs of them are written (<= max_slabs); H is bf16 or fp32 [nodes][ldh].  Mw % 256 == 0,
+ *       F == 256 and nodes >= 65536 run on the output-stationary kernel. */
+int hmp_gemm_bf16_dx(const uint16_t* d_dz, int32_t lddz, const uint16_t* d_dz2, int32_t lddz2, int32_t split, const float* d_w,
+                     int32_t ldw, const uint16_t* d_h, int32_t ldh, int32_t act, int32_t drop_on, float drop_scale, uint16_t* d_g,
+                     int32_t ldg, int32_t M, int32_t N, int32_t K, void* stream);
+int hmp_gemm_bf16_dw(const uint16_t* d_dz, int32_t lddz, const uint16_t* d_dz2, int32_t lddz2, int32_t split, const void* d_h,
+                     int32_t ldh, int32_t h_bf16, float* d_slabs, int32_t ldc, int64_t slab_stride, int32_t max_slabs,
+                     int32_t* n_slabs, int32_t Mw, int32_t F, int32_t nodes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 4. K3 -- GAT edge softmax + weighted aggregation, one row group of lanes per destination row.
@@ -186,6 +204,10 @@ typedef struct hmp_conv_spec {
   int32_t fill_mean;  /* GAT_edge self-loop attr: 1 = per-destination mean, 0 = zeros */
   int32_t shared_lin; /* GAT built from an int in_channels: lin_dst IS lin_src */
   int32_t active;     /* 0 = output never reaches the loss: skipped in forward and backward */
+  int32_t agg_first;  /* SAGE, src != dst: 1 = aggregate the source rows first, then project the (few) destination rows -- the order
+                       * [PyG] SAGEConv itself uses (lin_l(mean_j x_j)); exact algebra, chosen by the caller for
+                       * convs whose destination type is much smaller than the source type (objects -> rooms at 10^6 objects).
+                       * At most one such conv per source type and layer.  0: project every source row, gather the projected rows */
   float att_dropout;  /* GAT: dropout on the attention coefficients (GATConv(dropout=p)), training only */
   /* offsets (floats) into the flat parameter buffer, -1 = absent.
    * SAGE: w0 = lin_l.weight [f_out, f_src], b0 = lin_l.bias [f_out], w1 = lin_r.weight [f_out, f_dst]

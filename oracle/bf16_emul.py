@@ -17,6 +17,12 @@ backward, layer l
   * weight gradient = dZ^T [H | 1] with both operands as rounded above (the bias gradient is the ones column: column sums of the
     rounded root block).
 
+aggregate-first convs (``agg_first``: the (layer, edge type) pairs the engine evaluates in [PyG] SAGEConv's own order, mean of the
+source rows first -- objects -> rooms at >= 32 768 objects, ``hmp_conv_spec.agg_first``)
+  * the mean M of the source rows AS STORED (the fp32 input features in layer 0, bf16 activations later) is kept in fp32 and ROUNDED as the operand of the destination-sized GEMM M * W_l^T;
+    that product is the conv's block of Z[l][dst] (stored as bf16 in a hidden layer); backward: its block of dZ is the destination's
+    output gradient (as stored), dM = dZ_block * W_l stays fp32 and reaches the source rows BEFORE their activation mask;
+
 Because the rounding points depend on the engine's algebra (project first, then aggregate: SURVEY App. C.3), this restatement
 follows that algebra; with every rounding removed (``rounding=False``) it equals ``oracle.models.HeterogeneousNetwork`` up to
 float64 round-off, which ``tests/test_oracle_kat.py`` checks -- that is what ties it to the PyG restatement.
@@ -69,7 +75,7 @@ def _scatter_mean(msg, index, n):
 
 
 def sage_hetero_bf16(ora, batch, dtype=torch.float64, rounding: bool = True,
-                     dropout_fn: Optional[Callable] = None, training: bool = False):
+                     dropout_fn: Optional[Callable] = None, training: bool = False, agg_first=()):
     """(logits [N_rooms, C], loss, {parameter name: gradient}) of ``ora`` (an ``oracle.models.HeterogeneousNetwork`` with
     GraphSAGE convs, classification_task 'room') on ``batch`` under the bf16 storage contract above.  ``dropout_fn(x, p,
     training, tag)`` as in ``oracle.models`` (replays the engine's keep-masks)."""
@@ -105,7 +111,15 @@ def sage_hetero_bf16(ora, batch, dtype=torch.float64, rounding: bool = True,
                 zroot = fwd(zroot)  # root block of Z stored as bf16
             agg = 0
             for et in convs_t:
-                z = h_in[et[0]] @ fwd(leaf(key(et) + ".lin_l.weight").to(dtype)).t()
+                w_l = fwd(leaf(key(et) + ".lin_l.weight").to(dtype))
+                if (l, tuple(et)) in agg_first:  # mean of the STORED source rows first (fp32 input features in layer 0, bf16
+                    # activations after it: x[] as it stands), then the destination-sized projection
+                    m = _scatter_mean(x[et[0]].index_select(0, ei[et][0]), ei[et][1], x[t].size(0))
+                    z = fwd(m) @ w_l.t()
+                    z = bwd(fwd(z)) if not last else bwd(z)
+                    agg = agg + z
+                    continue
+                z = h_in[et[0]] @ w_l.t()
                 z = bwd(fwd(z)) if not last else bwd(z)  # Z / dZ stored as bf16 (hidden); dZ rounded as a GEMM operand (last)
                 agg = agg + _scatter_mean(z.index_select(0, ei[et][0]), ei[et][1], x[t].size(0))
             if last:

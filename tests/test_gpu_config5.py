@@ -154,9 +154,13 @@ def test_config5_bf16_mode_matches_the_bf16_contract_oracle(graph, monkeypatch):
     pred, loss, grads = engine_fwd_bwd(net, g)
     assert net.native().read_state()[1] == 0
     replay = make_replay(net)
+    # the convs the engine evaluated aggregate-first (objects -> rooms at this size): the contract rounds where the engine rounds
+    nat = net.native()
+    af = {(l, tuple(nat.layers[l].convs[c].edge_type)) for (l, c), on in nat._agg_first.items() if on}
+    assert af == {(l, ("objects", "objects_to_rooms", "rooms")) for l in range(3)}, af
     # the bf16 contract, accumulated in float64 and in float32, and the exact function (no rounding)
-    l64, s64, g64 = bf16_emul.sage_hetero_bf16(ora, graph, dtype=torch.float64, rounding=True, dropout_fn=replay, training=True)
-    l32, s32, g32 = bf16_emul.sage_hetero_bf16(ora, graph, dtype=torch.float32, rounding=True, dropout_fn=replay, training=True)
+    l64, s64, g64 = bf16_emul.sage_hetero_bf16(ora, graph, dtype=torch.float64, rounding=True, dropout_fn=replay, training=True, agg_first=af)
+    l32, s32, g32 = bf16_emul.sage_hetero_bf16(ora, graph, dtype=torch.float32, rounding=True, dropout_fn=replay, training=True, agg_first=af)
     lex, sex, gex = bf16_emul.sage_hetero_bf16(ora, graph, dtype=torch.float64, rounding=False, dropout_fn=replay, training=True)
     report = []
 

@@ -380,3 +380,100 @@ def test_fp32_activation_projection_weight_stationary_kernel(monkeypatch, M, N):
         outs[mode] = Cc
     monkeypatch.delenv("HMP_GEMM_WS")
     assert torch.equal(outs["1"], outs["0"])
+
+
+# ---- round 3: operand-stationary backward GEMMs of the 10^6-node regime (csrc/gemm_bf16_bwd.hip) ---------------------------------
+def _act_factor(h, act, drop_on, scale):
+    """act'(h) . dropout factor from the STORED activations: a dropped element is -0 (sign bit of a zero)"""
+    hf = h.float()
+    dropped = (h.view(torch.int16) == -32768) if drop_on else torch.zeros_like(hf, dtype=torch.bool)
+    if act == 1:
+        f = (hf > 0).float() * scale
+    elif act == 2:  # stored h = scale * elu(x): elu'(x) * scale = scale for x > 0, else scale * e^x = h + scale
+        f = torch.where(hf > 0, torch.full_like(hf, scale), hf + scale)
+    else:
+        f = torch.full_like(hf, scale)
+    return torch.where(dropped, torch.zeros_like(hf), f)
+
+
+@pytest.mark.parametrize("M,K,split,mask", [(40037, 768, 512, "relu_drop"), (33000, 512, 256, "relu_drop"), (36000, 256, 0, "none"),
+                                            (40000, 768, 0, "relu"), (34567, 512, 0, "elu_drop")])
+def test_bf16_input_gradient_weight_stationary_kernel(monkeypatch, M, K, split, mask):
+    """hmp_gemm_bf16_dx: G = act'(H) . (dZ * Wp) with dZ in one or two bf16 pieces, against float64 on the rounded operands and
+    against the tiled kernel (HMP_GEMM_DX=0) on the same call: every K class, ragged M, padded leading dimensions, the
+    activation / dropout mask read from the stored bf16 activations."""
+    lib = _lib.require_device()
+    N, pad = 256, 8
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    k1 = split if split else K
+    A1 = (torch.randn(M, k1 + pad, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    A2 = (torch.randn(M, (K - k1) + pad, device="cuda", generator=g) * 0.5).to(torch.bfloat16) if split else None
+    W = torch.randn(K, N + 4, device="cuda", generator=g) * 0.1
+    act = {"none": 0, "relu": 1, "relu_drop": 1, "elu_drop": 2}[mask]
+    drop_on = int(mask.endswith("drop"))
+    scale = 1.0 / 0.75 if drop_on else 1.0
+    H = None
+    if mask != "none":
+        H = (torch.randn(M, N + pad, device="cuda", generator=g)).to(torch.bfloat16)
+        if drop_on:
+            dropm = torch.rand(M, N + pad, device="cuda", generator=g) < 0.25
+            H = torch.where(dropm, torch.tensor(-0.0, device="cuda", dtype=torch.bfloat16), H)
+            assert int((H.view(torch.int16) == -32768).sum()) > M  # the -0 pattern survives
+    Afull = torch.cat([A1[:, :k1], A2[:, : K - k1]], dim=1) if split else A1[:, :K]
+    ref = Afull.double() @ W[:, :N].to(torch.bfloat16).double()
+    if H is not None:
+        ref = ref * _act_factor(H[:, :N], act, drop_on, scale).double()
+    outs = {}
+    for mode in ("2", "0"):  # 2: the weight-stationary kernel for every K class (K = 768 is off by default: slower than the tiled one)
+        monkeypatch.setenv("HMP_GEMM_DX", mode)
+        G = torch.full((M, N + pad), 7.0, device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.hmp_gemm_bf16_dx(A1.data_ptr(), k1 + pad, A2.data_ptr() if split else None, (K - k1) + pad if split else 0, split,
+                                        W.data_ptr(), N + 4, H.data_ptr() if H is not None else None, N + pad, act, drop_on, scale,
+                                        G.data_ptr(), N + pad, M, N, K, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        err = ((G[:, :N].double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+        assert err < 8e-3, (mode, err)  # bf16 output: half an ulp of 2^-8 relative
+        assert torch.all(G[:, N:] == 7.0)
+        outs[mode] = G[:, :N].clone()
+    monkeypatch.delenv("HMP_GEMM_DX")
+    # same products, same k order, fp32 accumulation on the same matrix pipe: the bf16 results agree (a last-bit difference in the
+    # fp32 sum can move a bf16 rounding: allow a handful)
+    diff = (outs["2"].float() - outs["0"].float()).abs() > 0
+    assert int(diff.sum()) <= M * N // 2000, int(diff.sum())
+
+
+@pytest.mark.parametrize("nodes,Mw,split,h_bf16", [(70001, 768, 512, 1), (66000, 512, 256, 1), (80000, 768, 512, 0), (65536, 256, 0, 1)])
+def test_bf16_weight_gradient_output_stationary_kernel(monkeypatch, nodes, Mw, split, h_bf16):
+    """hmp_gemm_bf16_dw: slabs of dW = dZ^T * [H | 1] over node ranges; their sum against float64 on the rounded operands and against
+    the tiled kernel (HMP_GEMM_DW=0): bf16 and fp32 H, dZ in two pieces, a node count that leaves a partial last chunk."""
+    import ctypes as C
+
+    lib = _lib.require_device()
+    F, pad, ldc = 256, 8, 260
+    g = torch.Generator(device="cuda").manual_seed(nodes + Mw)
+    k1 = split if split else Mw
+    A1 = (torch.randn(nodes, k1 + pad, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    A2 = (torch.randn(nodes, (Mw - k1) + pad, device="cuda", generator=g) * 0.5).to(torch.bfloat16) if split else None
+    Hf = torch.randn(nodes, F + pad, device="cuda", generator=g)
+    Hm = Hf.to(torch.bfloat16) if h_bf16 else Hf
+    Afull = torch.cat([A1[:, :k1], A2[:, : Mw - k1]], dim=1) if split else A1[:, :Mw]
+    Hr = Hm[:, :F].to(torch.bfloat16).double()
+    ref = torch.cat([Afull.double().t() @ Hr, Afull.double().sum(0, keepdim=True).t()], dim=1)  # [Mw, F + 1]
+    sums = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HMP_GEMM_DW", mode)
+        max_slabs = 192
+        slabs = torch.full((max_slabs, Mw, ldc), float("nan"), device="cuda")
+        ns = C.c_int32(0)
+        _lib.check(lib.hmp_gemm_bf16_dw(A1.data_ptr(), k1 + pad, A2.data_ptr() if split else None, (Mw - k1) + pad if split else 0, split,
+                                        Hm.data_ptr(), F + pad, h_bf16, slabs.data_ptr(), ldc, Mw * ldc, max_slabs, C.byref(ns), Mw, F, nodes,
+                                        _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert 1 <= ns.value <= max_slabs
+        got = slabs[: ns.value, :, : F + 1].double().sum(0)
+        assert torch.isfinite(got).all(), mode
+        err = ((got - ref).abs() / ref.abs().clamp_min(10.0)).max().item()
+        assert err < 2e-4, (mode, err, ns.value)
+        sums[mode] = got
+    monkeypatch.delenv("HMP_GEMM_DW")
+    assert ((sums["1"] - sums["0"]).abs() / ref.abs().clamp_min(10.0)).max().item() < 2e-4

@@ -250,6 +250,15 @@ def test_bf16_contract_restatement_equals_pyg_restatement_without_rounding():
     loss = o64.loss(pred, y, y != 25)
     loss.backward()
     logits, l2, grads = bf16_emul.sage_hetero_bf16(ora, g, dtype=torch.float64, rounding=False)
+    # the aggregate-first evaluation of objects -> rooms (the engine's choice at >= 32 768 objects) is the same function too
+    af = {(l, ("objects", "objects_to_rooms", "rooms")) for l in range(3)}
+    la, l2a, ga = bf16_emul.sage_hetero_bf16(ora, g, dtype=torch.float64, rounding=False, agg_first=af)
+    torch.testing.assert_close(la, logits, atol=1e-10, rtol=1e-10)
+    torch.testing.assert_close(l2a, l2, atol=1e-10, rtol=1e-10)
+    for name, gr in grads.items():
+        assert (gr is None) == (ga[name] is None), name
+        if gr is not None:
+            torch.testing.assert_close(ga[name].double(), gr.double(), atol=1e-6, rtol=1e-6, msg=lambda m: f"agg-first {name}: {m}")
     # not 1e-12: the restatement sums the root weights / biases of a destination type in fp32 first (as the engine's pack does)
     torch.testing.assert_close(logits, pred.detach(), atol=5e-7, rtol=1e-6)
     torch.testing.assert_close(l2, loss.detach(), atol=5e-7, rtol=1e-6)
