@@ -275,14 +275,17 @@ def test_bf16_compute_mode_on_a_large_graph():
 
 
 @pytest.mark.parametrize("n_obj,n_rooms", [(40000, 400), (140000, 4200)])
-def test_bf16_mode_activation_storage_is_bit_identical(n_obj, n_rooms):
-    """bf16 compute mode, 256-wide hidden layers: the activations H of the hidden layers are written as bf16 by the aggregation
+def test_bf16_mode_activation_storage_is_bit_identical(n_obj, n_rooms, monkeypatch):
+    """(With every conv evaluated project-first, HMP_AGG_FIRST=0: an aggregate-first conv averages the STORED activations, so there
+    the storage type is part of the result -- tests/test_gpu_config5.py holds that path to the bf16-storage contract instead.)
+    bf16 compute mode, 256-wide hidden layers: the activations H of the hidden layers are written as bf16 by the aggregation
     and read as bf16 by the next projection, its weight gradient and the activation / dropout mask of its input gradient.
     Those GEMMs round H to bf16 on the way into LDS anyway and the dropout keep-bit is the sign of zero, so logits and every
     gradient must be BIT-identical to fp32-stored activations (HMP_H16=0), in training mode with dropout."""
     kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, dropout=0.25)
     # 40 000 / 400: 128x128 GEMM tiles (a 400-row companion problem, < 2^17 nodes); 140 000 / 4 200: the 256x256 tiles of
     # config 5 for all three GEMM forms (every problem >= 4096 rows, weight gradients over >= 2^17 nodes)
+    monkeypatch.setenv("HMP_AGG_FIRST", "0")
     g = workloads.big_hetero_graph(n_obj=n_obj, n_rooms=n_rooms, seed=9).to(DEV)
     _, net = build(kw, HeterogeneousNetwork, omodels.HeterogeneousNetwork)
     net.train()
