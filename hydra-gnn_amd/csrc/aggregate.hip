@@ -19,8 +19,8 @@ KT_DEFINE(agg)
 KT_BLOCKS_DEFINE(agg)
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
-constexpr int WIN_THREADS_CHAIN = 512;   // graph-local chain kernel: CHAIN_GROUPS groups of 256 threads (1024 threads would cap the
-constexpr int CHAIN_GROUPS = WIN_THREADS_CHAIN / 256;  // tile routines at 128 VGPRs: measured 1 201 spilled registers, 0.49 ms)
+[[maybe_unused]] constexpr int WIN_THREADS_CHAIN = 512;   // graph-local chain kernel: CHAIN_GROUPS groups of 256 threads (1024 threads would cap the
+[[maybe_unused]] constexpr int CHAIN_GROUPS = WIN_THREADS_CHAIN / 256;  // tile routines at 128 VGPRs: measured 1 201 spilled registers, 0.49 ms)
 
 // raw buffer descriptor over [base, base + bytes): loads past the end return 0 without touching memory
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
@@ -1049,6 +1049,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dx_kernel(const TAggArgs a) {
   KT_SPAN_END(48, si);
 }
 
+#ifdef HMP_EXPERIMENTS  // measured 5x slower than the multi-launch sequence (profiles/r02_c_graph_local_chain.md): kept out of the product library
 // ----- graph-local chain: every launch between the front kernel and the weight-gradient GEMM, in ONE launch ------------------
 // A batch is a disjoint union of scene graphs: no edge crosses graphs, so from the first aggregation to the last transposed
 // aggregation a graph depends on nothing but itself.  One 1024-thread workgroup owns one graph for ALL of those phases
@@ -1199,6 +1200,8 @@ __global__ __launch_bounds__(WIN_THREADS_CHAIN) void chain_kernel(const ChainArg
     }
   }
 }
+#endif  // HMP_EXPERIMENTS
+
 
 // ----- LDS sliding-window aggregation for the 10^6-row regime (bf16 rows of 256 elements = 512 bytes) ------------------------
 // Scene graphs are local: an object's neighbours are objects of the same room, and a graph builder numbers the objects of a
@@ -1727,6 +1730,7 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_bwd_win_kernel(const WinBwd a
   }
 }
 
+#ifdef HMP_EXPERIMENTS
 int chain_launch(const ChainArgs* d_args, int n_graphs, int fin_rows, int gs, size_t lds_bytes, hipStream_t st) {
   lds_bytes += ((sizeof(ChainArgs) + 15) / 16) * 16;  // + the LDS copy of the argument block
   HMP_CHECK_ARG(d_args && n_graphs > 0 && (gs == 16 || gs == 32) && lds_bytes <= 150 * 1024, "chain: bad launch (%d graphs, gs %d, %zu LDS bytes)", n_graphs, gs, lds_bytes);
@@ -1741,6 +1745,9 @@ int chain_launch(const ChainArgs* d_args, int n_graphs, int fin_rows, int gs, si
   HMP_LAUNCH_CHECK();
   return HMP_OK;
 }
+#else
+int chain_launch(const ChainArgs*, int, int, int, size_t, hipStream_t) { HMP_FAIL(HMP_E_UNSUPPORTED, "chain_launch: experiment build only (make EXPERIMENTS=1)"); }
+#endif
 
 // ----- dispatch ---------------------------------------------------------------------------------------
 // lanes needed = ceil(F / VEC); GS = next pow2 in [8, 64]; NV = ceil(lanes / GS) <= 4
@@ -1867,10 +1874,13 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
         w.d.win_in = wi;
         w.mean = a.mean;
         w.n_chunks = cdiv(w.d.n_rows, WR);
+        w.dbg = 0;
+#ifdef HMP_KTIME  // measurement-only switch (wrong results): profiling build only
         {
           const char* dv = getenv("HMP_WIN_DBG");
           w.dbg = dv ? atoi(dv) : 0;
         }
+#endif
         const int grid = agg_win_grid(w.n_chunks, w.chunks_per_block);
         if (a.hb16) hipLaunchKernelGGL((agg_fwd_win_kernel<true>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);
         else hipLaunchKernelGGL((agg_fwd_win_kernel<false>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);

@@ -670,10 +670,13 @@ static int ws_launch(const GemmProblem& p, hipStream_t st) {
   a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc; a.c_bf16 = p.c_bf16;
   a.n_slices = cdiv(p.N, WS_COLS);
   a.n_tiles = cdiv(p.M, WS_ROWS);
+  a.dbg = 0;
+#ifdef HMP_KTIME  // measurement-only switch (wrong results): profiling build only
   {
     const char* dv = getenv("HMP_WS_DBG");
     a.dbg = dv ? atoi(dv) : 0;
   }
+#endif
   static const int n_cu = [] {  // (queried once: the property call is not cheap)
     int dev = 0;
     hipDeviceProp_t prop;

@@ -74,8 +74,22 @@ struct ProfRec {
 
 }  // namespace
 
+// Test / A-B switches of the executor (environment variables), read ONCE per entry call -- forward, step -- into this block
+// (tests flip them between two calls on one net) instead of by getenv() wherever a decision is taken
+struct EnvSwitches {
+  bool plan_sliced = true;  // HMP_PLAN_SLICED=0: plan parts read the whole edge list (tests compare both builds)
+  bool front = true;        // HMP_FRONT=0: separate pack / projection / plan launches
+  bool ell = false;         // HMP_ELL=1 (experiment builds only): neighbour ids from the plan's ELL tables
+  bool z16 = true;          // HMP_Z16=0: keep fp32 projected rows / gradients in bf16 compute mode
+  bool h16 = true;          // HMP_H16=0: keep fp32 activations in bf16 compute mode
+  bool rootcopy = false;    // HMP_ROOTCOPY=1: the transposed aggregation copies the root block of dZ
+  bool tn_direct = true;    // HMP_TN=0: LDS-staged split-K kernel for the small-batch weight gradients
+  bool bf16_all = false;    // HMP_BF16_ALL=1: every GEMM of a bf16-mode net takes the bf16 kernel whatever its size
+};
+
 struct hmp_net {
   hmp_net_spec spec;
+  EnvSwitches env;
   int T, ET, L;
   int dim[HMP_MAX_LAYERS + 1][HMP_MAX_NODE_TYPES];  // feature width of H[l][t]
   int ld[HMP_MAX_LAYERS + 1][HMP_MAX_NODE_TYPES];   // leading dimension of our own H/G buffers (l >= 1)
@@ -183,6 +197,22 @@ struct hmp_net {
 };
 
 namespace {
+
+void read_env(hmp_net* n) {
+  auto is = [](const char* name, char c) { const char* v = getenv(name); return v && v[0] == c; };
+  EnvSwitches e;
+  e.plan_sliced = !is("HMP_PLAN_SLICED", '0');
+  e.front = !is("HMP_FRONT", '0');
+#ifdef HMP_EXPERIMENTS
+  e.ell = is("HMP_ELL", '1');
+#endif
+  e.z16 = !is("HMP_Z16", '0');
+  e.h16 = !is("HMP_H16", '0');
+  e.rootcopy = is("HMP_ROOTCOPY", '1');
+  e.tn_direct = !is("HMP_TN", '0');
+  e.bf16_all = is("HMP_BF16_ALL", '1');
+  n->env = e;
+}
 
 inline int fpad(int f) { return align4(f); }
 
@@ -813,8 +843,7 @@ void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb) {
     J.t_rowptr = P.d_t_rowptr; J.t_col = P.d_t_col; J.t_pos = P.d_t_pos;
     {  // graph-sorted edge list vouched for by the caller (hmp_batch::d_edge_ptr)
       const int ts = n->spec.edge_src[e], td = n->spec.edge_dst[e];
-      const char* sv = getenv("HMP_PLAN_SLICED");  // 0: read the whole edge list per part (tests compare both builds)
-      const bool on = !(sv && sv[0] == '0');
+      const bool on = n->env.plan_sliced;
       if (on && b->n_graphs > 0 && b->d_edge_ptr[e] && b->d_node_ptr[ts] && b->d_node_ptr[td]) {
         J.gp_edge = b->d_edge_ptr[e]; J.gp_src = b->d_node_ptr[ts]; J.gp_dst = b->d_node_ptr[td]; J.n_graphs = b->n_graphs;
       }
@@ -863,10 +892,8 @@ int h_ld(const hmp_net* n, int l, int t) { return is_input(n, l, t) ? n->batch.l
 // bf16 compute mode: only the throughput-bound regime (>= 1024 64x64 tiles in the call) leaves the exact fp32 kernel
 // HMP_BF16_ALL=1 (tests): every GEMM call of a bf16-mode net takes the bf16 kernel whatever its size, so that a graph the
 // float64 oracle can hold (4 x 10^4 objects) runs exactly the decisions of the 10^6-object regime (BASELINE config 5)
-inline bool bf16_all() {
-  const char* v = getenv("HMP_BF16_ALL");
-  return v && v[0] == '1';
-}
+static thread_local bool g_bf16_all = false;  // EnvSwitches::bf16_all of the call in progress (set by read_env's callers)
+inline bool bf16_all() { return g_bf16_all; }
 
 bool gemm_takes_bf16(const std::vector<GemmProblem>& ps, bool allow_bf16) {
   if (allow_bf16 && bf16_all()) return true;
@@ -905,8 +932,7 @@ void fill_plan_batch(hmp_net* n, const hmp_batch* b, PlanBatch& pb);
 // Front kernel arguments (layer-0 projection + plan + pack in one launch); false when the batch / network does not fit its
 // limits (the caller then launches pack, projection and plan separately).
 bool build_front(hmp_net* n, const hmp_batch* b, const float* d_params, FrontArgs& fa) {
-  const char* fv = getenv("HMP_FRONT");  // 0: separate pack / projection / plan launches (tests)
-  if ((fv && fv[0] == '0') || !n->d_pack_map) return false;
+  if (!n->env.front || !n->d_pack_map) return false;
   const hmp_net_spec& S = n->spec;
   const hmp_layer_spec& Ls = S.layers[0];
   const LayerLayout& Y = n->lay[0];
@@ -1106,10 +1132,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
   hipStream_t side = (n->use_branches && (n->branch_mask & 1)) ? n->side[0] : main_st;
   if (side != main_st) HMP_TRY(fork_to(n, main_st, side));
   n->fuse_now = fuse_small(n, b);
-  {
-    const char* v = getenv("HMP_ELL");  // 1: neighbour ids from the plan's ELL tables (measured slower, see kernels.h: off by default)
-    n->ell_on = v && v[0] == '1';
-  }
+  n->ell_on = n->env.ell;  // (experiment builds: neighbour ids from the plan's ELL tables; measured slower, see kernels.h)
   memset(n->h16, 0, sizeof(n->h16));
   n->reuse_plan = false;
   if (b->plan_valid) {
@@ -1183,8 +1206,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
         }
         z16 = fmax <= 256 && fmin > 128;
         for (GemmProblem& p : ps) z16 = z16 && (p.ldc & 3) == 0;
-        const char* zv = getenv("HMP_Z16");  // 0: keep fp32 projected rows (tests)
-        if (zv && zv[0] == '0') z16 = false;
+        if (!n->env.z16) z16 = false;
         if (z16)
           for (GemmProblem& p : ps) p.c_bf16 = 1;
       }
@@ -1335,8 +1357,7 @@ int forward_impl(hmp_net* n, const hmp_batch* b, const float* d_params, hipStrea
           }
           hb = work >= 1e9 || bf16_all();  // gemm_takes_bf16's work criterion
         }
-        const char* hv = getenv("HMP_H16");  // 0: keep fp32 activations (tests)
-        if (hv && hv[0] == '0') hb = false;
+        if (!n->env.h16) hb = false;
         if (hb) {
           a.hb16 = 1;
           for (int t = 0; t < n->T; ++t)
@@ -1518,10 +1539,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         dz16 = a.gb16 && n->compute_bf16 != 0;
         for (int s = 0; s < n->T && dz16; ++s)
           if (Y.ncols[s] > 0 && b->n_nodes[s] > 0 && (Y.ncols[s] % 256) != 0) dz16 = false;
-        {
-          const char* zv = getenv("HMP_Z16");
-          if (zv && zv[0] == '0') dz16 = false;
-        }
+        if (!n->env.z16) dz16 = false;
         a.dzb16 = dz16 ? 1 : 0;
         // the root block of dZ is a copy of the output gradient (d out / d z_root = 1): with both stored as bf16 and the block
         // on a 256-column boundary the two backward GEMMs read it where it is (GemmProblem::A2) and the copy -- 1 GB per layer
@@ -1529,10 +1547,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         rootless = dz16;
         for (int i = 0; i < a.n && rootless; ++i)
           if (a.s[i].groot && ((a.s[i].roff & 255) != 0 || a.s[i].Froot != 256 || (a.s[i].ldgr & 3) != 0)) rootless = false;
-        {
-          const char* rv = getenv("HMP_ROOTCOPY");  // 1: keep the copy (tests)
-          if (rv && rv[0] == '1') rootless = false;
-        }
+        if (n->env.rootcopy) rootless = false;
         if (rootless)
           for (int i = 0; i < a.n; ++i) a.s[i].groot = nullptr;
         if (n->chain_try && n->fuse_now && l == 0 && !a.gb16) {
@@ -1646,8 +1661,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
         }
         bool ok = fmax <= 256 && fmin > 128;
         for (GemmProblem& p : ps) ok = ok && (p.ldc & 3) == 0;
-        const char* zv = getenv("HMP_Z16");  // 0: keep fp32 rows (tests)
-        if (zv && zv[0] == '0') ok = false;
+        if (!n->env.z16) ok = false;
         if (ok) {
           for (GemmProblem& p : ps) p.c_bf16 = 1;
           g16[l] = true;
@@ -1693,9 +1707,8 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
             fmin = f < fmin ? f : fmin;
             fmax = f > fmax ? f : fmax;
           }
-          const char* zv = getenv("HMP_Z16");
           g16[l] = n->compute_bf16 != 0 && !n->fuse_now && n->lay[l - 1].kind != HMP_CONV_GAT && fmax <= 256 && fmin > 128 &&
-                   (n->ld[l][s] & 3) == 0 && !(zv && zv[0] == '0') && (b->n_nodes[s] >= 32768 || bf16_all());
+                   (n->ld[l][s] & 3) == 0 && n->env.z16 && (b->n_nodes[s] >= 32768 || bf16_all());
         }
         gb = l > 0 && g16[l];
         HMP_TRY(seg_mean_rows_t_launch(Q.dmrows, Q.ld_m, fpad(n->dim[l][s]), T.P->d_t_rowptr, T.P->d_t_col, T.degf, b->n_nodes[s],
@@ -1790,8 +1803,7 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     std::vector<int> ks;
     bool direct = n->fuse_now;
     if (direct) {  // register-direct TN kernel (one memory round trip per <= 192-node chunk); all-or-nothing per call
-      const char* tv = getenv("HMP_TN");  // 0: LDS-staged split-K kernel (tests)
-      if (tv && tv[0] == '0') direct = false;
+      if (!n->env.tn_direct) direct = false;
       for (size_t i = 0; i < wps.size() && direct; ++i)
         if (wps[i].K > TN_DIRECT_SLABS * 384 || wps[i].b_bf16 || wps[i].a_bf16) direct = false;
       for (size_t base = 0; base < wps.size() && direct; base += GEMM_MAX_PROB) {
@@ -1867,8 +1879,12 @@ extern "C" int hmp_net_create(const hmp_net_spec* spec, hmp_net** out) {
     n->dw_mode = db ? (db[0] == '1' ? 1 : 0) : -1;  // -1: decide per batch (see backward_impl)
     const char* fz = getenv("HMP_FUSE");
     n->fuse_mode = fz ? (fz[0] == '1' ? 1 : 0) : -1;
-    const char* cz = getenv("HMP_CHAIN");
+#ifdef HMP_EXPERIMENTS
+    const char* cz = getenv("HMP_CHAIN");  // graph-local chain launch: measured 5x slower (profiles/r02_c_graph_local_chain.md)
     n->chain_mode = cz ? (cz[0] == '1' ? 1 : 0) : -1;
+#else
+    n->chain_mode = 0;
+#endif
   }
   if (r != HMP_OK) {
     hmp_net_destroy(n);
@@ -1933,6 +1949,8 @@ extern "C" int hmp_net_bind_workspace(hmp_net* n, void* d_workspace, size_t byte
 extern "C" int hmp_net_forward(hmp_net* n, const hmp_batch* batch, const float* d_params, int32_t training, uint64_t seed,
                                uint32_t rng_step, const float** d_out, int32_t* ld_out, void* stream) {
   HMP_CHECK_ARG(n && batch && d_params && d_out && ld_out, "hmp_net_forward: null argument");
+  read_env(n);
+  g_bf16_all = n->env.bf16_all;
   n->training = training; n->seed = seed; n->rng_step = rng_step; n->step_dev = false;
   n->chain_try = false;
   n->deferred.clear();
@@ -1945,6 +1963,7 @@ extern "C" int hmp_net_forward(hmp_net* n, const hmp_batch* batch, const float* 
 extern "C" int hmp_net_backward(hmp_net* n, const float* d_gout, int32_t ld_gout, const float* d_params, float* d_grads,
                                 float* const* d_gx, void* stream) {
   HMP_CHECK_ARG(n && d_gout && d_grads && d_params, "hmp_net_backward: null argument");
+  g_bf16_all = n->env.bf16_all;  // (the switches of the forward this backward belongs to)
   return backward_impl(n, d_gout, ld_gout, d_grads, d_params, d_gx, (hipStream_t)stream);
 }
 
@@ -1976,6 +1995,7 @@ extern "C" int hmp_net_backward2(hmp_net* n, const float* d_gout, int32_t ld_gou
                                  const float* d_params, float* d_grads, float* const* d_gx, void* stream) {
   HMP_CHECK_ARG(n && d_grads && d_params && (d_gout || d_gout_aux), "hmp_net_backward2: null argument");
   HMP_CHECK_ARG(n->spec.aux_readout_type >= 0, "hmp_net_backward2: the net has one output (use hmp_net_backward)");
+  g_bf16_all = n->env.bf16_all;
   if (!d_gout) {  // no gradient for the first output: a zero block of its shape (G[L][readout] is free in the last layer)
     HMP_CHECK_ARG(n->have_fwd, "net: backward without a forward");
     const int rt = n->spec.readout_type, rows = n->batch.n_nodes[rt];
@@ -1992,6 +2012,8 @@ extern "C" int hmp_net_step_fwd_bwd(hmp_net* n, const hmp_batch* batch, const fl
   HMP_CHECK_ARG(n->spec.aux_readout_type < 0, "hmp_net_step_fwd_bwd: the fused step computes one cross entropy (single-output nets)");
   HMP_CHECK_ARG(batch->d_labels != nullptr, "hmp_net_step_fwd_bwd: labels required");
   hipStream_t st = (hipStream_t)stream;
+  read_env(n);
+  g_bf16_all = n->env.bf16_all;
   n->training = args->training; n->seed = args->seed; n->rng_step = 0; n->step_dev = true;
   n->d_step = args->d_step ? args->d_step : &n->d_state->step;
   n->ce_labels = batch->d_labels; n->ce_ignored = args->ignored_label; n->ce_done = false;

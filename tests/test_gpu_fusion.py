@@ -465,6 +465,12 @@ def test_standalone_sequence_at_the_reference_batch_scale_matches_the_oracle(mon
             torch.testing.assert_close(grads[name].cpu().double(), p.grad, atol=ATOL * scale, rtol=RTOL, msg=lambda m: f"{name}: {m}")
 
 
+# the measured-and-rejected experiments (graph-local chain launch, ELL neighbour tables) are compiled out of the product library
+# (hygiene): their tests run against `make EXPERIMENTS=1` builds only (HMP_TEST_EXPERIMENTS=1)
+experiments_only = pytest.mark.skipif(os.environ.get("HMP_TEST_EXPERIMENTS") != "1", reason="experiment build only (make EXPERIMENTS=1)")
+
+
+@experiments_only
 @pytest.mark.parametrize("n_graphs,hidden,layers", [(1, 64, 3), (7, 64, 3), (32, 64, 3), (5, 32, 2), (6, 64, 4)])
 def test_graph_local_chain_launch_is_bit_identical(n_graphs, hidden, layers, monkeypatch):
     """OPT-IN (HMP_CHAIN=1; measured slower than the multi-launch sequence, profiles/r02_c_graph_local_chain.md).
@@ -512,6 +518,7 @@ def test_graph_local_chain_launch_is_bit_identical(n_graphs, hidden, layers, mon
     assert torch.equal(p0, p1)
 
 
+@experiments_only
 def test_graph_local_chain_is_skipped_without_graph_boundaries(monkeypatch):
     """A batch that does not say where its graphs begin (no ptr / max_graph_nodes) takes the multi-launch sequence; so does the
     autograd path (forward / backward as separate calls)."""
@@ -537,6 +544,7 @@ def test_graph_local_chain_is_skipped_without_graph_boundaries(monkeypatch):
     assert launches["chain"] == 0 and launches["aggregate_fwd"] == 3
 
 
+@experiments_only
 @pytest.mark.parametrize("kw_over,n_graphs,train", [({}, 8, False), ({}, 64, True), ({"hidden_dim": 128, "num_layers": 4}, 8, False),
                                                     ({"hidden_dim": 32, "num_layers": 2}, 5, False)])
 def test_ell_id_table_gathers_are_bit_identical(monkeypatch, kw_over, n_graphs, train):

@@ -196,3 +196,22 @@ def test_config4_fixture_scene_graphs():
         same += int(t["counts"] == ref["counts"] and signature(t) == signature(ref))
         print(f"fixture graph {gi}: native {t['counts']} reference {ref['counts']}")
     print(f"{same} of {int(z['n_graphs'])} fixture H-trees coincide with the reference's")
+
+
+def test_reference_htree_is_not_a_function_of_the_id_order_on_the_fixture_graphs():
+    """tests/golden/htree_order_dependence.json (made by make_htree_order_fixture.py with the reference's own generator): the same
+    scene graph with node ids i and 3 i + 1 -- an order-preserving relabelling, same insertion order -- gives the reference
+    DIFFERENT labelled H-trees (even different node counts) on all six config-4 fixture graphs and on loopy_b / loopy_c, and the
+    same tree on the eight tie-free cases and loopy_a.  networkx walks CPython sets of the ids when it breaks ties (iteration
+    order = id mod table size), so no rule stated on the ids' order -- csrc/htree.cpp: smallest id -- can reproduce both answers.
+    Where the reference IS invariant, the native construction returns its tree (tests above)."""
+    import json
+
+    rows = {r["graph"]: r for r in json.load(open(os.path.join(os.path.dirname(GOLDEN), "htree_order_dependence.json")))["rows"]}
+    key = "reference_invariant_under_order_preserving_relabelling"
+    for name in UNIQUE + ["loopy_a"]:
+        assert rows[name][key] is True, name
+    for gi in range(6):
+        r = rows[f"config4_fixture_{gi}"]
+        assert r[key] is False and r["max_id"] >= 32, r
+    assert sum(1 for gi in range(6) if rows[f"config4_fixture_{gi}"]["htree_nodes"][0] != rows[f"config4_fixture_{gi}"]["htree_nodes"][1]) >= 4
