@@ -150,6 +150,9 @@ struct PlanJob {
   int n_graphs;
   // scratch
   int *cnt_in, *cnt_out, *cur_in, *cur_out;  // must be zero on entry (one contiguous block); left zero on exit
+  int* flags;  // multi-launch build: [0] / [1] = PlanBatch::build_id of the last build that found the list NOT ordered by destination /
+               // source (or holding an invalid edge); part of the zeroed block.  An edge list that arrives ordered by destination --
+               // what graph builders emit -- IS its CSR (position = edge id): no scatter, no rank pass for that direction
   int *tmp_in, *tmp_out, *t_eid, *pos_of_eid;
   int *tmpc_in, *tmpc_out;  // multi-launch build: the other endpoint of every scratch slot
 };
@@ -158,6 +161,9 @@ struct PlanBatch {
   int need_tpos;   // build t_pos (only GAT's source-major backward reads it)
   int clear_first; // memset the counters before the launch (caller-provided scratch of unknown content)
   int built_small; // out: plan_launch took the single-launch build (the one that also writes PlanJob::ell / t_ell)
+  int build_id;    // multi-launch build: stamp of this build (see PlanJob::flags)
+  int* flags_all;  // [2 * n] = job 0's flag block used for ALL jobs: entry 2 j + dir (one pointer in the batch header: reading a
+                   // per-job pointer through a per-lane job index made the compiler copy the 4 KB argument block to scratch)
   int64_t edge_start[HMP_MAX_EDGE_TYPES + 1];
   int64_t row_start[2 * HMP_MAX_EDGE_TYPES + 1];  // rows of (job, dir): dir 0 = by dst, 1 = by src
   PlanJob j[HMP_MAX_EDGE_TYPES];
