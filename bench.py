@@ -75,7 +75,7 @@ def parse():
                          "time has been timed; `steps` stays K, `timed_regions` says how many")
     ap.add_argument("--fresh-batches", action="store_true",
                     help="extra leg (config 2 / 3): every step takes a DIFFERENT batch, collated on the device from a resident "
-                         "dataset of 64 x batch graphs (store.BatchStream: one host call + one kernel) and described afresh -- "
+                         "dataset of min(64 x batch, max(2048, 4 x batch)) graphs (store.BatchStream: one host call + one kernel) and described afresh -- "
                          "the loop a trainer actually runs; reported as `fresh_batches` beside the headline")
     ap.add_argument("--gat-edge", action="store_true",
                     help="config 3: the GAT_edge variant (SURVEY 8(d): inputs after compute_relative_pos -- objects 303-d, rooms 3-d, "
@@ -536,7 +536,7 @@ def main():
         from hydra_gnn_amd import workloads
         from hydra_gnn_amd.store import GraphStore
 
-        n_pool = 64 * n_graphs
+        n_pool = min(64 * n_graphs, max(2048, 4 * n_graphs))  # 2048 graphs at the default batch, 4 batches' worth at 2048
         rng_p = np.random.Generator(np.random.PCG64(workloads.BASE_SEED + 77))
         pool = [workloads.mp3d_like_graph(rng_p) for _ in range(n_pool)]
         store = GraphStore(pool, dev)

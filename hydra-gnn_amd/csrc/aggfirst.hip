@@ -67,41 +67,77 @@ __device__ __forceinline__ float t_mask(float h, int act, bool keep, float scale
   return scale;
 }
 
-// one wavefront per source row: G[j, :] = mask(H[j, :]) . sum_{k in CSC row j} dM[t_col[k], :] * degf[t_col[k]]
+// G[j, :] = mask(H[j, :]) . sum_{k in CSC row j} dM[t_col[k], :] * degf[t_col[k]].  One wavefront walks TR consecutive source rows at a
+// time with every row's chain (extent -> destination id -> reciprocal degree + dM row) and its H row requested together: a source row
+// has one or two such edges (the conv qualified by E <= 2 N_src), so a wave that owns a single row is a chain of four dependent round
+// trips with one 512-byte row in flight (measured 2.5 TB/s at config 5; TR rows per wave keep TR of them in flight).
+constexpr int TR = 4;
 template <bool HB, bool GB>
 __global__ __launch_bounds__(256) void seg_mean_rows_t_kernel(const float* __restrict__ dm, int lddm, int F, const int* __restrict__ t_rowptr,
                                                               const int* __restrict__ t_col, const float* __restrict__ degf, int n_rows,
                                                               const void* __restrict__ h, int ldh, int act, int drop_on, float dscale,
                                                               void* __restrict__ g, int ldg) {
-  const int row = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-  if (row >= n_rows) return;
+  const int row0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * TR;
+  if (row0 >= n_rows) return;
   const int lane = threadIdx.x & 63;
-  const int b = t_rowptr[row], e = t_rowptr[row + 1];
-  for (int c0 = lane * 4; c0 < F; c0 += 256) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = b; k < e; ++k) {
-      const int i = t_col[k];
-      const float wd = degf[i];
-      const float4 v = ld4(dm + (int64_t)i * lddm + c0);
-      acc.x += wd * v.x; acc.y += wd * v.y; acc.z += wd * v.z; acc.w += wd * v.w;
-    }
-    if (h) {
-      float4 hv;
-      if constexpr (HB) hv = ld4(reinterpret_cast<const uint16_t*>(h) + (int64_t)row * ldh + c0);
-      else hv = ld4(reinterpret_cast<const float*>(h) + (int64_t)row * ldh + c0);
-      const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
-      float f[4];
+  int b[TR], e[TR];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) f[q] = t_mask(hh[q], act, !drop_on || __float_as_uint(hh[q]) != 0x80000000u, dscale);
-      acc.x *= f[0]; acc.y *= f[1]; acc.z *= f[2]; acc.w *= f[3];
+  for (int u = 0; u < TR; ++u) {
+    const int r = min(row0 + u, n_rows - 1);
+    b[u] = t_rowptr[r];
+    e[u] = row0 + u < n_rows ? t_rowptr[r + 1] : b[u];
+  }
+  for (int c0 = lane * 4; c0 < F; c0 += 256) {
+    float4 hv[TR];
+    if (h) {
+#pragma unroll
+      for (int u = 0; u < TR; ++u) {
+        const int r = min(row0 + u, n_rows - 1);
+        if constexpr (HB) hv[u] = ld4(reinterpret_cast<const uint16_t*>(h) + (int64_t)r * ldh + c0);
+        else hv[u] = ld4(reinterpret_cast<const float*>(h) + (int64_t)r * ldh + c0);
+      }
     }
-    if constexpr (GB) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4 o;
-      o[0] = (__bf16)acc.x; o[1] = (__bf16)acc.y; o[2] = (__bf16)acc.z; o[3] = (__bf16)acc.w;
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(g) + (int64_t)row * ldg + c0) = o;
-    } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g) + (int64_t)row * ldg + c0) = acc;
+    float4 acc[TR];
+    int i0[TR];
+#pragma unroll
+    for (int u = 0; u < TR; ++u) i0[u] = e[u] > b[u] ? t_col[b[u]] : -1;  // first edge of every row: the TR chains run side by side
+    float wd0[TR];
+    float4 v0[TR];
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      wd0[u] = 0.f;
+      v0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0[u] >= 0) { wd0[u] = degf[i0[u]]; v0[u] = ld4(dm + (int64_t)i0[u] * lddm + c0); }
+    }
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      acc[u] = make_float4(wd0[u] * v0[u].x, wd0[u] * v0[u].y, wd0[u] * v0[u].z, wd0[u] * v0[u].w);
+      for (int k = b[u] + 1; k < e[u]; ++k) {  // further edges of the row, in edge order
+        const int i = t_col[k];
+        const float wd = degf[i];
+        const float4 v = ld4(dm + (int64_t)i * lddm + c0);
+        acc[u].x += wd * v.x; acc[u].y += wd * v.y; acc[u].z += wd * v.z; acc[u].w += wd * v.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      if (row0 + u >= n_rows) break;
+      float4 a4 = acc[u];
+      if (h) {
+        const float hh[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
+        float f[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = t_mask(hh[q], act, !drop_on || __float_as_uint(hh[q]) != 0x80000000u, dscale);
+        a4.x *= f[0]; a4.y *= f[1]; a4.z *= f[2]; a4.w *= f[3];
+      }
+      if constexpr (GB) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 o;
+        o[0] = (__bf16)a4.x; o[1] = (__bf16)a4.y; o[2] = (__bf16)a4.z; o[3] = (__bf16)a4.w;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(g) + (int64_t)(row0 + u) * ldg + c0) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(g) + (int64_t)(row0 + u) * ldg + c0) = a4;
+      }
     }
   }
 }
@@ -130,7 +166,7 @@ int seg_mean_rows_t_launch(const float* dm, int lddm, int F, const int* t_rowptr
                            const void* h, int ldh, int h_bf16, int act, int drop_on, float dscale, void* g, int ldg, int g_bf16, hipStream_t st) {
   if (n_rows <= 0) return HMP_OK;
   HMP_CHECK_ARG((F & 3) == 0 && (lddm & 3) == 0 && (ldg & 3) == 0 && (!h || (ldh & 3) == 0), "seg_mean_rows_t: rows must be whole 4-element vectors");
-  const dim3 grid(cdiv(n_rows, 4)), block(256);
+  const dim3 grid(cdiv(n_rows, 4 * TR)), block(256);
 #define HMP_T_LAUNCH(HB_, GB_) \
   hipLaunchKernelGGL((seg_mean_rows_t_kernel<HB_, GB_>), grid, block, 0, st, dm, lddm, F, t_rowptr, t_col, degf, n_rows, h, ldh, act, drop_on, dscale, g, ldg)
   if (h_bf16 && g_bf16) HMP_T_LAUNCH(true, true);
