@@ -45,7 +45,11 @@ struct Acc<4> {
     const float r = 1.0f / d;
     v.x = fmaf(o.v.x, r, v.x); v.y = fmaf(o.v.y, r, v.y); v.z = fmaf(o.v.z, r, v.z); v.w = fmaf(o.v.w, r, v.w);
   }
-  __device__ __forceinline__ void add_mul(const Acc& o, float r) { v.x += o.v.x * r; v.y += o.v.y * r; v.z += o.v.z * r; v.w += o.v.w * r; }
+  // explicit fused multiply-adds (two v_pk_fma_f32): left to the compiler, an 8-edge batch became 2 packed multiplies + 2 packed adds per
+  // edge and a 2-edge batch 2 packed fmas -- a third more vector instructions, and a rounding that depended on the batch shape
+  __device__ __forceinline__ void add_mul(const Acc& o, float r) {
+    v.x = fmaf(o.v.x, r, v.x); v.y = fmaf(o.v.y, r, v.y); v.z = fmaf(o.v.z, r, v.z); v.w = fmaf(o.v.w, r, v.w);
+  }
   __device__ __forceinline__ void div(float d) { v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
   __device__ __forceinline__ float& at(int i) { return (&v.x)[i]; }
 };
@@ -57,7 +61,7 @@ struct Acc<1> {
   __device__ __forceinline__ void store(float* p) const { *p = v; }
   __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
   __device__ __forceinline__ void add_div(const Acc& o, float d) { v = fmaf(o.v, 1.0f / d, v); }
-  __device__ __forceinline__ void add_mul(const Acc& o, float r) { v += o.v * r; }
+  __device__ __forceinline__ void add_mul(const Acc& o, float r) { v = fmaf(o.v, r, v); }
   __device__ __forceinline__ void div(float d) { v /= d; }
   __device__ __forceinline__ float& at(int) { return v; }
 };
@@ -1442,43 +1446,97 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
     const bool fits = win_offsets(rp, nq, off, eb);
     const int wlo = max(r_c - WM, 0), whi = min(r_c + WR + WM, n_rows);  // rows the ring holds now
     {  // (!fits, block-uniform: a chunk with more ids than the LDS slice holds reads extents / ids from global memory, no window)
-      // phase B: root rows of all WG rows of this wave requested together
-      uint2 root[WG];
-#pragma unroll
-      for (int g = 0; g < WG; ++g) {
-        const int row = r_c + g * WIN_WAVES + wave;
-        root[g] = make_uint2(0u, 0u);
-        if (row < n_rows && D.zroot)
-          root[g] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(D.zroot) + (int64_t)row * D.ldzr + D.roff + c0);
+      // Round 3: the counters had the waves of this kernel waiting 57 % of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES) and the vector
+      // unit 56 % busy -- a row was a chain of ~7 dependent waits (extents, ids and row batches per edge type).  Now (a) the extents of
+      // all of the wave's rows are ONE lane-parallel LDS read per chunk and reach the scalar unit by readlane; (b) the neighbour ids
+      // of the NEXT row's window list and of its deferred list are requested while this row computes; (c) the edge type after the
+      // window one (rooms -> objects: one or two global rows) has its rows requested BEFORE the window batches and is added after
+      // them -- same accumulators, same order of additions: bit-identical to the plain kernels.
+      const int WQ = D.win_in, DQ = (fits && WQ + 1 < nq) ? WQ + 1 : -1;  // wave-uniform
+      int rpv = 0;  // lane 8 q + 2 g + h: extent h of the wave's g-th row, edge type q
+      if (fits && (lane >> 3) < nq) rpv = rp[(lane >> 3) * WRP + ((lane & 7) >> 1) * WIN_WAVES + wave + (lane & 1)];
+      const int offW = sel_q(off, WQ) - sel_q(eb, WQ), offD = DQ >= 0 ? sel_q(off, DQ) - sel_q(eb, DQ) : 0;  // + extent = id slot
+      auto ids_of = [&](int g, int q, int offq) {  // ids 0..63 of row g's list of edge type q (staged chunk only)
+        const int b = __builtin_amdgcn_readlane(rpv, q * 8 + g * 2), e = __builtin_amdgcn_readlane(rpv, q * 8 + g * 2 + 1);
+        return lane < e - b ? idc[offq + b + lane] : 0;
+      };
+      int idw = 0, idd = 0;
+      if (fits) {
+        idw = ids_of(0, WQ, offW);
+        if (DQ >= 0) idd = ids_of(0, DQ, offD);
       }
+      // phase B: the root row travels one row ahead as well
+      auto root_of = [&](int g) {
+        const int row = r_c + g * WIN_WAVES + wave;
+        uint2 r = make_uint2(0u, 0u);
+        if (g < WG && row < n_rows && D.zroot)
+          r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(D.zroot) + (int64_t)row * D.ldzr + D.roff + c0);
+        return r;
+      };
+      uint2 root = root_of(0);
       // phase C: sums in edge order, one accumulator per edge type.  The neighbour id of an edge is wave-uniform (readlane), so
       // its row comes either from the LDS ring (one ds_read_b64 at a scalar-computed slot) or from global memory (scalar base +
       // lane offset): a scalar branch per edge, no per-lane address arithmetic, 16 loads in flight per batch.
 #pragma unroll 1
       for (int g = 0; g < WG; ++g) {
         const int rl = g * WIN_WAVES + wave, row = r_c + rl;
-        if (row >= n_rows) continue;
+        if (row >= n_rows) break;  // rows grow with g
         [[maybe_unused]] const unsigned long long kt_r = KT_NOW();
+        const uint2 root_n = root_of(g + 1);
+        int idw_n = 0, idd_n = 0;  // (b) the next row's ids: in flight while this row's batches run
+        if (fits && g + 1 < WG) {
+          idw_n = ids_of(g + 1, WQ, offW);
+          if (DQ >= 0) idd_n = ids_of(g + 1, DQ, offD);
+        }
+        // (c) deferred edge type: a list of one or two rows is requested here and consumed after the window list
+        u32x2 vd[2] = {{0u, 0u}, {0u, 0u}};
+        int cntD = 0;
+        if (DQ >= 0) {
+          const int bD = __builtin_amdgcn_readlane(rpv, DQ * 8 + g * 2), eD = __builtin_amdgcn_readlane(rpv, DQ * 8 + g * 2 + 1);
+          if (eD - bD >= 1 && eD - bD <= 2) {
+            cntD = eD - bD;
+            const AggIn& I = D.in[DQ];
+            const uint16_t* zq = reinterpret_cast<const uint16_t*>(I.z) + I.coff;
+            const __amdgpu_buffer_rsrc_t rs = win_rsrc(zq, (unsigned)I.n_src * (unsigned)(I.ldz * 2) - (unsigned)(I.coff * 2));
+            const __amdgpu_buffer_rsrc_t rs_null = win_rsrc(zq, 0u);
+            const int gov = lane < cntD ? idd * (I.ldz * 2) : 0;
+            vd[0] = __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8, __builtin_amdgcn_readlane(gov, 0), 0);
+            vd[1] = __builtin_amdgcn_raw_buffer_load_b64(cntD > 1 ? rs : rs_null, lane * 8, __builtin_amdgcn_readlane(gov, 1), 0);
+          }
+        }
         Acc<4> tot;
         tot.zero();
-        if (D.zroot) widen_bf16x4(tot, sel_root(root, g));
+        if (D.zroot) widen_bf16x4(tot, root);
         tot.add(biasv);
 #pragma unroll 1
         for (int q = 0; q < nq; ++q) {
           const AggIn& I = D.in[q];
-          const int b = fits ? uni(rp[q * WRP + rl]) : I.rowptr[row], e = fits ? uni(rp[q * WRP + rl + 1]) : I.rowptr[row + 1];
+          if (q == DQ && cntD) {  // the deferred list: its rows have landed behind the window batches
+            Acc<4> acc, w;
+            acc.zero();
+            widen_bf16x4(w, make_uint2(vd[0][0], vd[0][1]));
+            acc.add(w);
+            widen_bf16x4(w, make_uint2(vd[1][0], vd[1][1]));
+            acc.add(w);
+            tot.add_div(acc, a.mean ? (float)cntD : 1.f);
+            continue;
+          }
+          const int b = fits ? __builtin_amdgcn_readlane(rpv, q * 8 + g * 2) : I.rowptr[row];
+          const int e = fits ? __builtin_amdgcn_readlane(rpv, q * 8 + g * 2 + 1) : I.rowptr[row + 1];
           if (e == b) continue;
           const uint16_t* zq = reinterpret_cast<const uint16_t*>(I.z) + I.coff;
           const int ldq = I.ldz;
           const __amdgpu_buffer_rsrc_t rs = win_rsrc(zq, (unsigned)I.n_src * (unsigned)(ldq * 2) - (unsigned)(I.coff * 2));
           const __amdgpu_buffer_rsrc_t rs_null = win_rsrc(zq, 0u);
           const int offq = fits ? sel_q(off, q) + (b - sel_q(eb, q)) : 0;
-          const bool wq = fits && q == D.win_in;
+          const bool wq = fits && q == WQ;
           Acc<4> acc;
           acc.zero();
           for (int base = 0; base < e - b; base += 64) {
             const int cnt = min(e - b - base, 64);
-            const int idv = lane < cnt ? (fits ? idc[offq + base + lane] : I.col[b + base + lane]) : 0;
+            int idv = 0;
+            if (wq && base == 0) idv = idw;  // requested one row ago
+            else if (lane < cnt) idv = fits ? idc[offq + base + lane] : I.col[b + base + lane];
             // lane u prepares edge u: BOTH sources are read for every edge, branch-free (the compiler drains the memory counters
             // at every control-flow join; flat loads into LDS run at a fraction of the ds_read rate): the LDS read aims at the
             // ring slot or at the all-zero row, the buffer read at the global row or -- through a descriptor of zero records --
@@ -1540,6 +1598,9 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
         }
         store_z<HB>(tot, D.out, (int64_t)row * D.ldo + c0);
         KT_ADD(30, kt_r);
+        idw = idw_n;
+        idd = idd_n;
+        root = root_n;
       }
     }
     KT_ADD(21, kt_c);
