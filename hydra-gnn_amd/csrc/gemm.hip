@@ -172,6 +172,12 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS, BK>& t, const float* __
 // consecutive k of one row): written plainly, 32 lanes (k = 0,4,8,..) would hit 2 banks (4*LD = 16 mod 32: 16-way
 // conflict), so row r of k-row k is ROTATED to column (r + k/4) mod ROWS: the 32 lanes then land on 32 different banks
 // (bank = 17*(k/4) + r + const), and the MFMA operand fetch (32 consecutive r of one k) stays conflict-free.
+// column of the rotated image: x in [0, 2 ROWS); ROWS need not be a power of two (192-column tiles)
+template <int ROWS>
+__device__ __forceinline__ int wrap_rows(int x) {
+  if constexpr ((ROWS & (ROWS - 1)) == 0) return x & (ROWS - 1);
+  else return x >= ROWS ? x - ROWS : x;
+}
 template <int ROWS, int BK>
 __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& t, float* __restrict__ s, int kcontig) {
   constexpr int NV = TileRegs<ROWS, BK>::NV;
@@ -182,7 +188,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS, BK>& t, float* _
     const int q = tid + i * 256;
     if (kcontig) {
       const int r = q / (BK / 4), k4 = (q % (BK / 4)) * 4;
-      const int rr = (r + (k4 >> 2)) & (ROWS - 1);
+      const int rr = wrap_rows<ROWS>(r + (k4 >> 2));
       s[(k4 + 0) * LD + rr] = t.v[i].x;
       s[(k4 + 1) * LD + rr] = t.v[i].y;
       s[(k4 + 2) * LD + rr] = t.v[i].z;
@@ -309,9 +315,9 @@ __global__ __launch_bounds__(256, (MI * NI > 1) ? 2 : 3) void gemm_kernel(const 
       const int rot = (kw * KS + kk) >> 2;
       float av[MI], bv[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) av[i] = As[k * LDA + (a_kcontig ? ((ma + 32 * i + rot) & (BM - 1)) : ma + 32 * i)];  // undo the store rotation
+      for (int i = 0; i < MI; ++i) av[i] = As[k * LDA + (a_kcontig ? wrap_rows<BM>(ma + 32 * i + rot) : ma + 32 * i)];  // undo the store rotation
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bv[j] = Bs[k * LDB + (b_kcontig ? ((mb + 32 * j + rot) & (BN - 1)) : mb + 32 * j)];
+      for (int j = 0; j < NI; ++j) bv[j] = Bs[k * LDB + (b_kcontig ? wrap_rows<BN>(mb + 32 * j + rot) : mb + 32 * j)];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -585,6 +591,8 @@ static bool tall_takes(const GemmProblem& p) {
 
 int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm: %d problems", gb.n);
+  // launches of >= 10^9 multiply-adds: fp32 accuracy from six bf16 piece products per element product (gemm_x3.hip)
+  if (gemm_x3_takes(gb, want_split)) return gemm_x3_launch(gb, want_split, max_slabs, st);
   if (want_split) {  // weight gradients over >= 32768 nodes with <= 192 stacked columns: the tall kernel (one launch for all of them)
     TallBatch tb;
     memset(&tb, 0, sizeof(tb));
@@ -665,6 +673,15 @@ int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
     for (int i = 0; i < gb.n; ++i) min_n = gb.p[i].N < min_n ? gb.p[i].N : min_n;
     if (big_ok && min_n >= 256 && work >= 1e9 && (tiles128 >= 256 || (want_split && max_k >= 8192)))
       return launch_cfg<2, 2, 32, 2, 2>(gb, want_split, max_slabs, st);
+    // round 3: outputs of 129 .. 192 columns (the three stacked 64-column blocks of an MP3D layer at the reference's batch size:
+    // 190 k rows x 192) take the WHOLE width in one workgroup -- 64 x 192 tiles, 1 x 3 accumulator tiles per wave: the node rows
+    // are read once instead of three times and an A fragment feeds three MFMAs (246 VGPRs, no spill; the 128 x 192 form with
+    // 2 x 3 tiles per wave spills 96 registers at two workgroups per CU and was not kept).  HMP_GEMM_WIDE=0: the 64x64 form
+    int max_n = 0;
+    for (int i = 0; i < gb.n; ++i) max_n = gb.p[i].N > max_n ? gb.p[i].N : max_n;
+    const char* wv = getenv("HMP_GEMM_WIDE");
+    if (!(wv && wv[0] == '0') && !want_split && min_n > 128 && max_n <= 192 && work >= 1e9)
+      return launch_cfg<2, 2, 32, 1, 3>(gb, want_split, max_slabs, st);
     return launch_cfg<2, 2, 32>(gb, want_split, max_slabs, st);
   }
   if (max_k <= 64) return launch_cfg<1, 1, 64>(gb, want_split, max_slabs, st);

@@ -321,6 +321,7 @@ def test_gemm_128x128_register_tiling_is_bit_identical_to_64x64(ta, tb, monkeypa
         torch.cuda.synchronize()
         return c
 
+    monkeypatch.setenv("HMP_GEMM_X3", "0")  # (this test compares two tile shapes of the fp32-MFMA kernel)
     big = run()
     monkeypatch.setenv("HMP_GEMM_BIG", "0")
     small = run()
@@ -477,3 +478,80 @@ def test_bf16_weight_gradient_output_stationary_kernel(monkeypatch, nodes, Mw, s
         sums[mode] = got
     monkeypatch.delenv("HMP_GEMM_DW")
     assert ((sums["1"] - sums["0"]).abs() / ref.abs().clamp_min(10.0)).max().item() < 2e-4
+
+
+@pytest.mark.parametrize("shape", [(70001, 192, 306, 1, 306, 306), (40000, 192, 64, 0, 64, 192), (33000, 130, 80, 1, 84, 84)])
+def test_fp32_gemm_whole_width_tiles(shape, monkeypatch):
+    """Outputs of 129 .. 192 columns over >= 10^9 multiply-adds (an MP3D layer at the reference's batch size: 190 k x 192) run on
+    64 x 192 tiles -- one workgroup per 64 rows, three accumulator tiles per wave, the B image 192 columns wide (not a power of
+    two: the rotated LDS image wraps by comparison).  The k order of every output element is unchanged, so the product is
+    bit-identical to the 64x64 form (HMP_GEMM_WIDE=0) and within fp32 round-off of float64; row pitch 306 = 8-byte rows."""
+    from hydra_gnn_amd import _lib
+
+    lib = _lib.require_device()
+    M, N, K, tb, lda, ldb = shape
+    torch.manual_seed(6)
+    A = torch.randn(M, lda, device=dev())
+    B = torch.randn(N, ldb, device=dev()) if tb else torch.randn(K, ldb, device=dev())
+
+    def run():
+        C = torch.full((M, N + 3), float("nan"), device=dev())
+        _lib.check(lib.hmp_gemm_f32(A.data_ptr(), lda, 0, B.data_ptr(), ldb, tb, C.data_ptr(), N + 3, M, N, K, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return C
+
+    monkeypatch.setenv("HMP_GEMM_X3", "0")  # (this test compares two tile shapes of the fp32-MFMA kernel)
+    C1 = run()
+    monkeypatch.setenv("HMP_GEMM_WIDE", "0")
+    C0 = run()
+    monkeypatch.delenv("HMP_GEMM_WIDE")
+    assert torch.isnan(C1[:, N:]).all() and not torch.isnan(C1[:, :N]).any()
+    assert torch.equal(C1[:, :N], C0[:, :N])
+    ref = A[:, :K].double() @ (B[:, :K].double().t() if tb else B[:K, :N].double())
+    assert (C1[:, :N].double() - ref).abs().max().item() < 1e-4 * max(K, 64) ** 0.5
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K,lda_pad,ldb_pad", [
+    (0, 1, 70001, 192, 306, 0, 0),     # NT, the batch-2048 layer-0 projection: rows of 306 floats (8-byte rows), ragged M
+    (0, 1, 16384 + 37, 389, 306, 0, 0),  # NT, ragged everywhere
+    (0, 1, 9000, 515, 307, 0, 0),      # NT, odd pitch: element loads
+    (0, 0, 90000, 64, 192, 0, 0),      # NN (input gradient), N below a tile
+    (0, 0, 20011, 300, 260, 2, 2),     # NN, row-contiguous B with a partial column tile, padded pitches
+    (1, 0, 192, 306, 190000, 0, 0),    # TN (weight gradient): row-contiguous operands, B with pitch 306
+    (1, 0, 515, 131, 40000, 1, 3),     # TN, odd pitches
+])
+def test_fp32_gemm_on_the_bf16_pipe_by_three_way_split(ta, tb, M, N, K, lda_pad, ldb_pad, monkeypatch):
+    """Launches of >= 10^9 multiply-adds run hmp_gemm_f32 on gemm_x3_kernel: operands split exactly into three bf16 pieces, six piece
+    products per element product on v_mfma_f32_32x32x16_bf16.  Accuracy bar = the fp32-MFMA kernel's own: both within 2e-6 x the
+    product's scale of the float64 product (|error| of an fp32 dot product of K terms), and the split form not worse than 2x the
+    fp32-MFMA form's error.  NT / NN / TN operand layouts, ragged tiles, 16-byte / 8-byte / unaligned rows; columns past N untouched."""
+    from hydra_gnn_amd import _lib
+
+    lib = _lib.require_device()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    ar, ac = (K, M) if ta else (M, K)
+    br, bc = (N, K) if tb else (K, N)
+    A = torch.randn(ar, ac + lda_pad, device=dev(), generator=g)
+    B = torch.randn(br, bc + ldb_pad, device=dev(), generator=g) * 0.1
+    a64 = A[:, :ac].double()
+    b64 = B[:, :bc].double()
+    ref = (a64.t() if ta else a64) @ (b64.t() if tb else b64)
+
+    def run():
+        C = torch.full((M, N + 5), float("nan"), device=dev())
+        _lib.check(lib.hmp_gemm_f32(A.data_ptr(), A.stride(0), ta, B.data_ptr(), B.stride(0), tb, C.data_ptr(), C.stride(0), M, N, K,
+                                    _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.isnan(C[:, N:]).all() and not torch.isnan(C[:, :N]).any()
+        return C[:, :N].double()
+
+    monkeypatch.setenv("HMP_GEMM_X3", "2")  # (2: every launch form, also the split-K one the executor keeps on the tall kernel)
+    x3 = run()
+    monkeypatch.setenv("HMP_GEMM_X3", "0")
+    f32 = run()
+    assert not torch.equal(x3, f32)  # the split kernel really ran
+    scale = (a64.abs().mean() * b64.abs().mean() * K).item()  # ~ sum of |products|
+    e3 = (x3 - ref).abs().max().item()
+    e32 = (f32 - ref).abs().max().item()
+    assert e3 <= 2e-6 * scale, (e3, scale)
+    assert e3 <= 2.0 * e32 + 1e-7 * scale, (e3, e32)

@@ -9,8 +9,8 @@ swept the forward GEMM instantiations into the backward family and missed `agg_b
     front           front_kernel
     plan            plan_*_kernel
     pack            pack_kernel
-    gemm_fwd        gemm_kernel<.., FORM = 0, ..> | gemm_bf16_kernel<.., FORM = 0> | gemm_bf16_ws_kernel
-    gemm_bwd        gemm_kernel<.., FORM = 1 | 2 | 3, ..> | gemm_bf16_kernel<.., FORM = 1 | 2 | 3> | gemm_tn_direct_kernel |
+    gemm_fwd        gemm_kernel<.., FORM = 0, ..> | gemm_bf16_kernel<.., FORM = 0> | gemm_x3_kernel<., FORM = 0> | gemm_bf16_ws_kernel
+    gemm_bwd        gemm_kernel<.., FORM = 1 | 2 | 3, ..> | gemm_bf16_kernel / gemm_x3_kernel<.., FORM = 1 | 2 | 3> | gemm_tn_direct_kernel |
                     gemm_tn_tall_kernel | gemm_bf16_dx_kernel | gemm_bf16_dw_kernel
     agg_fwd         agg_proj_fwd_kernel | agg_fwd_kernel | agg_fwd_win_kernel | agg_fwd_mm_kernel | seg_mean_rows_kernel
     agg_bwd         agg_bwd_dx_kernel | agg_bwd_kernel | agg_bwd_win_kernel | agg_bwd_mm_kernel | seg_mean_rows_t_kernel
@@ -58,6 +58,9 @@ def kernel_family(name: str) -> Optional[str]:
             return "gemm_mixed"
         return "gemm_fwd" if a[3] == "0" else "gemm_bwd"
     a = _template_args(name, "gemm_bf16_kernel")
+    if a is not None:
+        return "gemm_fwd" if a[-1] == "0" else "gemm_bwd"
+    a = _template_args(name, "gemm_x3_kernel")  # <ONES, FORM>
     if a is not None:
         return "gemm_fwd" if a[-1] == "0" else "gemm_bwd"
     for fam, pat in _SIMPLE:
