@@ -29,10 +29,25 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int X3_NT = 256, X3_ROWS = 128, X3_BK = 32, X3_NV = X3_ROWS * X3_BK / 4 / X3_NT;  // 4 float4 slots per thread and operand
-constexpr int X3_PITCH = X3_BK + 8;    // [row][k] image: 40 bf16 = 80 bytes per row (odd multiple of 16 bytes: 8 consecutive rows cover all banks)
-constexpr int X3_RP = X3_ROWS + 8;     // [k][row] image: 136 bf16 per k row
-constexpr int X3_PLANE = (X3_ROWS * X3_PITCH > X3_BK * X3_RP) ? X3_ROWS * X3_PITCH : X3_BK * X3_RP;  // 5120 elements
+constexpr int X3_BK = 32;  // K stage
+// Tile shape: <256 threads, 128 x 128, 2 x 2 waves of 64 x 64>, two workgroups per CU, 60 KB of LDS each.  These products are bound
+// by the operand traffic between L2 and the CUs (measured ~4.5 TB/s over the chip: the tile loads 32 KB per K stage for 48 MFMAs per
+// wave -- the matrix pipe waits).  A <512 threads, 256 x 256, 4 x 2 waves of 64 x 128> shape (twice the bytes for four times the
+// work) was written against the same template and does not fit the register file: 128 accumulator registers + three pieces of
+// every fragment + the staging registers spill 500-1000 registers at the 256 a wave gets with 8 waves per CU -- not built.
+template <int NT_, int ROWS_, int WMW_, int WNW_>
+struct X3Cfg {
+  static constexpr int NT = NT_, ROWS = ROWS_, WMW = WMW_, WNW = WNW_;
+  static constexpr int MI = ROWS / WMW / 32, NI = ROWS / WNW / 32;  // 32x32 MFMA tiles per wave
+  static constexpr int NV = ROWS * X3_BK / 4 / NT;                  // float4 slots per thread and operand (4)
+  static constexpr int PITCH = X3_BK + 8;  // [row][k] image: 40 bf16 = 80 bytes per row (odd multiple of 16 bytes: 8 consecutive rows cover all banks)
+  static constexpr int RP = ROWS + 8;      // [k][row] image: bf16 elements per k row
+  static constexpr int PLANE = (ROWS * PITCH > X3_BK * RP) ? ROWS * PITCH : X3_BK * RP;
+  static constexpr int LDS_BYTES = 6 * PLANE * 2;
+};
+using X3Small = X3Cfg<256, 128, 2, 2>;
+constexpr int X3_NV = 4;
+static_assert(X3Small::NV == X3_NV, "four float4 slots per thread and operand");
 
 struct Regs {
   float4 v[X3_NV];
@@ -44,12 +59,12 @@ struct Regs {
 // The loader only ISSUES loads, all of them at clamped in-range addresses and without a branch in between; x3_mask zeroes what lies
 // outside the operand when the stage is consumed, one iteration later (a select right here would make the compiler wait for each load
 // before the MFMAs it is meant to overlap with: gemm.hip).
-template <int VEC>
+template <class C, int VEC>
 __device__ __forceinline__ void x3_load(Regs& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int k0, int kend) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < X3_NV; ++i) {
-    const int q = tid + i * X3_NT;
+    const int q = tid + i * C::NT;
     const float* src;
     int o1 = 1, o2 = 2, o3 = 3;
     if (kcontig) {
@@ -62,7 +77,7 @@ __device__ __forceinline__ void x3_load(Regs& t, const float* __restrict__ p, in
       if (VEC == 2) o2 = (gkc + 2 < kend) ? 2 : 0;
       if (VEC == 1) { o1 = (gkc + 1 < kend) ? 1 : 0; o2 = (gkc + 2 < kend) ? 2 : 0; o3 = (gkc + 3 < kend) ? 3 : 0; }
     } else {
-      const int k = q / (X3_ROWS / 4), r4 = (q % (X3_ROWS / 4)) * 4;
+      const int k = q / (C::ROWS / 4), r4 = (q % (C::ROWS / 4)) * 4;
       const int gk = k0 + k, c = r0 + r4;
       const float* row = p + (int64_t)(gk < kend ? gk : k0) * ld;
       if (VEC == 1) {  // partial tile: every column clamped into the operand
@@ -85,11 +100,12 @@ __device__ __forceinline__ void x3_load(Regs& t, const float* __restrict__ p, in
   }
 }
 
+template <class C>
 __device__ __forceinline__ void x3_mask(Regs& t, int kcontig, int r0, int R, int k0, int kend) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < X3_NV; ++i) {
-    const int q = tid + i * X3_NT;
+    const int q = tid + i * C::NT;
     if (kcontig) {
       const int r = q / (X3_BK / 4), k4 = (q % (X3_BK / 4)) * 4;
       const int gk = k0 + k4;
@@ -97,7 +113,7 @@ __device__ __forceinline__ void x3_mask(Regs& t, int kcontig, int r0, int R, int
       t.v[i] = make_float4(rl && gk + 0 < kend ? t.v[i].x : 0.f, rl && gk + 1 < kend ? t.v[i].y : 0.f, rl && gk + 2 < kend ? t.v[i].z : 0.f,
                            rl && gk + 3 < kend ? t.v[i].w : 0.f);
     } else {
-      const int k = q / (X3_ROWS / 4), c = r0 + (q % (X3_ROWS / 4)) * 4;
+      const int k = q / (C::ROWS / 4), c = r0 + (q % (C::ROWS / 4)) * 4;
       const bool kl = k0 + k < kend;
       t.v[i] = make_float4(kl && c + 0 < R ? t.v[i].x : 0.f, kl && c + 1 < R ? t.v[i].y : 0.f, kl && c + 2 < R ? t.v[i].z : 0.f,
                            kl && c + 3 < R ? t.v[i].w : 0.f);
@@ -106,11 +122,12 @@ __device__ __forceinline__ void x3_mask(Regs& t, int kcontig, int r0, int R, int
 }
 
 // the exact three-way split of four consecutive elements -> one 8-byte write per plane
+template <class C>
 __device__ __forceinline__ void x3_store(const Regs& t, __bf16* __restrict__ s, int kcontig) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < X3_NV; ++i) {
-    const int q = tid + i * X3_NT;
+    const int q = tid + i * C::NT;
     const float x[4] = {t.v[i].x, t.v[i].y, t.v[i].z, t.v[i].w};
     bf16x4 p1, p2, p3;
 #pragma unroll
@@ -124,26 +141,27 @@ __device__ __forceinline__ void x3_store(const Regs& t, __bf16* __restrict__ s, 
     int o;
     if (kcontig) {
       const int r = q / (X3_BK / 4), k4 = (q % (X3_BK / 4)) * 4;
-      o = r * X3_PITCH + k4;
+      o = r * C::PITCH + k4;
     } else {  // natural [k][row] image
-      const int k = q / (X3_ROWS / 4), r4 = (q % (X3_ROWS / 4)) * 4;
-      o = k * X3_RP + r4;
+      const int k = q / (C::ROWS / 4), r4 = (q % (C::ROWS / 4)) * 4;
+      o = k * C::RP + r4;
     }
     *reinterpret_cast<bf16x4*>(s + o) = p1;
-    *reinterpret_cast<bf16x4*>(s + X3_PLANE + o) = p2;
-    *reinterpret_cast<bf16x4*>(s + 2 * X3_PLANE + o) = p3;
+    *reinterpret_cast<bf16x4*>(s + C::PLANE + o) = p2;
+    *reinterpret_cast<bf16x4*>(s + 2 * C::PLANE + o) = p3;
   }
 }
 
 // MFMA operand (8 consecutive k of row `rowbase + lane % 32`, k half lane / 32) of k step ks from one plane (see gemm_bf16.hip: bf_fetch)
+template <class C>
 __device__ __forceinline__ bf16x8 x3_fetch(const __bf16* __restrict__ s, int kcontig, int rowbase, int ks, int lane) {
-  if (kcontig) return *reinterpret_cast<const bf16x8*>(s + (rowbase + (lane & 31)) * X3_PITCH + ks * 16 + 8 * (lane >> 5));
+  if (kcontig) return *reinterpret_cast<const bf16x8*>(s + (rowbase + (lane & 31)) * C::PITCH + ks * 16 + 8 * (lane >> 5));
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
   const int k0 = ks * 16 + 8 * (g >> 1);
-  const __bf16* a0 = s + (k0 + q) * X3_RP + rowbase + 16 * (g & 1) + 4 * p;
+  const __bf16* a0 = s + (k0 + q) * C::RP + rowbase + 16 * (g & 1) + 4 * p;
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * X3_RP));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * C::RP));
   union { s16x4 h[2]; bf16x8 v; } u;
   u.h[0] = lo;
   u.h[1] = hi;
@@ -161,46 +179,48 @@ __device__ __forceinline__ float x3_act_mask(float h, int act, bool keep, float 
 // around the loads is a control-flow join after every operand's loads, and hipcc drains the memory counter at a join -- every
 // stage then waited for its own prefetch right where it was issued (ISA: global_load x 4, s_waitcnt vmcnt(0), global_load x 8,
 // s_waitcnt vmcnt(0)), which is what held the first version of this kernel at the fp32-MFMA kernel's speed.
-template <bool ONES, int AV, int BV>
+template <class C, bool ONES, int AV, int BV>
 __device__ __forceinline__ void x3_loop(const GemmProblem& P, int a_kc, int b_kc, int m0, int n0, int kbeg, int kend, __bf16* As, __bf16* Bs,
-                                        f32x16 (&acc)[2][2], f32x16 (&acc1)[ONES ? 2 : 1], bool ones_here, int wm, int wn, int lane) {
-  constexpr int MI = 2, NI = 2;
+                                        f32x16 (&acc)[C::MI][C::NI], f32x16 (&acc1)[ONES ? C::MI : 1], bool ones_here, int wm, int wn, int lane) {
+  constexpr int MI = C::MI, NI = C::NI;
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
   // DEPTH register sets, loads DEPTH stages ahead (2 where the registers allow it: a stage is ~1 500 cycles of MFMAs, shorter than a
-  // trip to HBM under load; the ones-column forms hold two more accumulator tiles and keep one set)
-  constexpr int DEPTH = ONES ? 1 : 2;
+  // trip to HBM under load; the ones-column forms and the big tile hold more accumulator tiles and keep one set)
+  constexpr int DEPTH = (ONES || MI * NI > 4) ? 1 : 2;
   Regs ra0, rb0, ra1, rb1;
   auto load = [&](Regs& ra, Regs& rb, int k0) {
-    x3_load<AV>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
-    x3_load<BV>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
+    x3_load<C, AV>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
+    x3_load<C, BV>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
   };
   auto stage = [&](Regs& ra, Regs& rb, int kt) {
-    x3_mask(ra, a_kc, m0, P.M, kt, kend);
-    x3_mask(rb, b_kc, n0, P.n_real, kt, kend);
-    x3_store(ra, As, a_kc);
-    x3_store(rb, Bs, b_kc);
+    x3_mask<C>(ra, a_kc, m0, P.M, kt, kend);
+    x3_mask<C>(rb, b_kc, n0, P.n_real, kt, kend);
+    x3_store<C>(ra, As, a_kc);
+    x3_store<C>(rb, Bs, b_kc);
     __syncthreads();
     if (kt + DEPTH * X3_BK < kend) load(ra, rb, kt + DEPTH * X3_BK);  // this set's next turn
 #pragma unroll
     for (int ks = 0; ks < X3_BK / 16; ++ks) {
-      bf16x8 av[3][MI], bv[3][NI];
+      // the A fragments of the k step stay in registers (3 pieces x MI), the B fragments come one column tile at a time
+      bf16x8 av[3][MI];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) av[p][i] = x3_fetch(As + p * X3_PLANE, a_kc, wm * 64 + i * 32, ks, lane);
+        for (int i = 0; i < MI; ++i) av[p][i] = x3_fetch<C>(As + p * C::PLANE, a_kc, wm * (MI * 32) + i * 32, ks, lane);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bv[p][j] = x3_fetch(Bs + p * X3_PLANE, b_kc, wn * 64 + j * 32, ks, lane);
+      for (int j = 0; j < NI; ++j) {
+        bf16x8 bv[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bv[p] = x3_fetch<C>(Bs + p * C::PLANE, b_kc, wn * (NI * 32) + j * 32, ks, lane);
+        // smallest terms first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int tp = 0; tp < 6; ++tp)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[tp]][i], bv[PB[tp]], acc[i][j], 0, 0, 0);
       }
-      // smallest terms first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int tp = 0; tp < 6; ++tp)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[tp]][i], bv[PB[tp]][j], acc[i][j], 0, 0, 0);
       if constexpr (ONES) {
         if (ones_here) {  // column sums of A: every piece against ones
 #pragma unroll
@@ -225,11 +245,12 @@ __device__ __forceinline__ void x3_loop(const GemmProblem& P, int a_kc, int b_kc
 }
 
 // FORM: 0 NT, 1 NN, 2 TN, 3 per problem at run time (mixed launches)
-template <bool ONES, int FORM>
-__global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
-  constexpr int MI = 2, NI = 2;
-  __shared__ __attribute__((aligned(16))) __bf16 As[3 * X3_PLANE];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * X3_PLANE];
+template <class C, bool ONES, int FORM>
+__global__ __launch_bounds__(C::NT, C::NT == 256 ? 2 : 1) void gemm_x3_kernel(const GemmBatch gb) {
+  constexpr int MI = C::MI, NI = C::NI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
+  __bf16* As = reinterpret_cast<__bf16*>(x3_lds);
+  __bf16* Bs = As + 3 * C::PLANE;
   int pi = 0;
   while (pi + 1 < gb.n && (int)blockIdx.x >= gb.p[pi + 1].tile_start) ++pi;
   const GemmProblem& P = gb.p[pi];
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
   const int z = local % P.ksplit, t = local / P.ksplit;
   const int grp = t / (8 * P.tiles_n), within = t % (8 * P.tiles_n);
   const int rows_in_grp = min(8, P.tiles_m - grp * 8);
-  const int m0 = (grp * 8 + within % rows_in_grp) * X3_ROWS, n0 = (within / rows_in_grp) * X3_ROWS;
+  const int m0 = (grp * 8 + within % rows_in_grp) * C::ROWS, n0 = (within / rows_in_grp) * C::ROWS;
   const int kbeg = z * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
   const int a_kc = FORM == 3 ? (P.trans_a ? 0 : 1) : (FORM == 2 ? 0 : 1);
@@ -249,10 +270,10 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     return ((ld & 3) == 0 && (a & 15) == 0) ? 4 : (((ld & 1) == 0 && (a & 7) == 0) ? 2 : 1);
   };
-  const int a_vec = (a_kc || m0 + X3_ROWS <= P.M) ? vec_of(P.A, P.lda) : 1;
-  const int b_vec = (b_kc || n0 + X3_ROWS <= P.n_real) ? vec_of(P.B, P.ldb) : 1;
+  const int a_vec = (a_kc || m0 + C::ROWS <= P.M) ? vec_of(P.A, P.lda) : 1;
+  const int b_vec = (b_kc || n0 + C::ROWS <= P.n_real) ? vec_of(P.B, P.ldb) : 1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm = w & 1, wn = w >> 1;
+  const int wm = w % C::WMW, wn = w / C::WMW;
   const bool ones_here = ONES && P.aug_ones && n0 == 0 && wn == 0;  // wave-uniform
 
   f32x16 acc[MI][NI];
@@ -269,8 +290,8 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-          const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+          const int row = m0 + wm * (MI * 32) + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+          const int col = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
           acc[i][j][r] = (row < P.M && col < P.N) ? P.Cadd[(int64_t)row * P.ldadd + col] : 0.f;
         }
   }
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
 
   // the K loop, instantiated per loader pair: the choice must not sit INSIDE the loop (see x3_loop)
   const int mode = a_vec * 8 + b_vec;
-#define X3_LOOP(AV_, BV_) x3_loop<ONES, AV_, BV_>(P, a_kc, b_kc, m0, n0, kbeg, kend, As, Bs, acc, acc1, ones_here, wm, wn, lane)
+#define X3_LOOP(AV_, BV_) x3_loop<C, ONES, AV_, BV_>(P, a_kc, b_kc, m0, n0, kbeg, kend, As, Bs, acc, acc1, ones_here, wm, wn, lane)
   switch (mode) {
     case 4 * 8 + 4: X3_LOOP(4, 4); break;
     case 2 * 8 + 4: X3_LOOP(2, 4); break;
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
 
   // D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); epilogue as gemm.hip (no branch
   // between memory operations)
-  float* C = P.C + (int64_t)z * P.slab_stride;
+  float* Cp = P.C + (int64_t)z * P.slab_stride;
   const int Mrows = P.M, Ncols = P.N, ldc = P.ldc, ldh = P.ldh, act = P.act;
   const bool amask = P.epi == EPI_ACTMASK;
   const bool dropon = P.drop_on != 0;
@@ -305,8 +326,8 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-      const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+      const int col = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
+      const int rbase = m0 + wm * (MI * 32) + i * 32 + 4 * (lane >> 5);
       const bool cok = col < Ncols && !(ONES && P.aug_ones && col >= P.n_real);  // (the ones column comes from acc1)
       const int colc = col < Ncols ? col : 0;
       float hv[16];
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
           const bool keep = !dropon || (__float_as_uint(hv[r]) != 0x80000000u);  // dropped elements were stored as -0.0f
           v *= x3_act_mask(hv[r], act, keep, dscale);
         }
-        if (cok && row < Mrows) C[(int64_t)row * ldc + col] = v;
+        if (cok && row < Mrows) Cp[(int64_t)row * ldc + col] = v;
       }
     }
   if (ONES && ones_here && (lane & 31) == 0) {  // column 0 of the ones product -> C[:, n_real]
@@ -333,10 +354,74 @@ __global__ __launch_bounds__(X3_NT, 2) void gemm_x3_kernel(const GemmBatch gb) {
     for (int i = 0; i < (ONES ? MI : 1); ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < P.M) C[(int64_t)row * P.ldc + P.n_real] = acc1[i][r];
+        const int row = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < P.M) Cp[(int64_t)row * P.ldc + P.n_real] = acc1[i][r];
       }
   }
+}
+
+template <class C>
+int x3_launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
+  bool any_ones = false;
+  int start = 0, all_tiles = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    const GemmProblem& p = gb.p[i];
+    any_ones = any_ones || p.aug_ones != 0;
+    all_tiles += cdiv(p.M, C::ROWS) * cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::ROWS);
+  }
+  const int target = C::NT == 256 ? 1024 : 512;  // workgroups over the whole launch when split-K supplies them
+  for (int i = 0; i < gb.n; ++i) {
+    GemmProblem& p = gb.p[i];
+    p.tiles_m = cdiv(p.M, C::ROWS);
+    p.tiles_n = cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::ROWS);  // the ones column rides in the first column tile
+    const int tiles = p.tiles_m * p.tiles_n;
+    int ks = 1;
+    if (want_split && tiles > 0) {  // every slab gets at least one K stage
+      ks = target / (all_tiles > 0 ? all_tiles : 1);
+      const int max_by_k = cdiv(p.K, X3_BK);
+      if (ks > max_by_k) ks = max_by_k;
+      if (ks > max_slabs) ks = max_slabs;
+      if (ks < 1) ks = 1;
+    }
+    int kchunk = cdiv(cdiv(p.K, ks), X3_BK) * X3_BK;
+    if (kchunk < X3_BK) kchunk = X3_BK;
+    ks = p.K > 0 ? cdiv(p.K, kchunk) : 1;
+    p.ksplit = ks;
+    p.kchunk = kchunk;
+    p.tile_start = start;
+    start += tiles * ks;
+  }
+  gb.total_tiles = start;
+  if (start == 0) return HMP_OK;
+  int form = -1;
+  for (int i = 0; i < gb.n; ++i) {
+    const GemmProblem& p = gb.p[i];
+    const int f = (!p.trans_a && p.trans_b) ? 0 : (!p.trans_a && !p.trans_b) ? 1 : (p.trans_a && !p.trans_b) ? 2 : 3;
+    form = (form == -1 || form == f) ? f : 3;
+  }
+  static bool attr_done = false;  // (per configuration: one static per template instance)
+  if (!attr_done) {
+#define X3_ATTR(ONES_, FORM_) \
+  HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<C, ONES_, FORM_>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES))
+    X3_ATTR(true, 2); X3_ATTR(true, 3); X3_ATTR(false, 0); X3_ATTR(false, 1); X3_ATTR(false, 2); X3_ATTR(false, 3);
+#undef X3_ATTR
+    attr_done = true;
+  }
+#define X3_LAUNCH(ONES_, FORM_) hipLaunchKernelGGL((gemm_x3_kernel<C, ONES_, FORM_>), dim3(start), dim3(C::NT), C::LDS_BYTES, st, gb)
+  if (any_ones) {
+    if (form == 2) X3_LAUNCH(true, 2);
+    else X3_LAUNCH(true, 3);
+  } else {
+    switch (form) {
+      case 0: X3_LAUNCH(false, 0); break;
+      case 1: X3_LAUNCH(false, 1); break;
+      case 2: X3_LAUNCH(false, 2); break;
+      default: X3_LAUNCH(false, 3); break;
+    }
+  }
+#undef X3_LAUNCH
+  HMP_LAUNCH_CHECK();
+  return HMP_OK;
 }
 
 }  // namespace
@@ -362,58 +447,11 @@ bool gemm_x3_takes(const GemmBatch& gb, bool want_split) {
 
 int gemm_x3_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {
   HMP_CHECK_ARG(gb.n >= 0 && gb.n <= GEMM_MAX_PROB, "gemm_x3: %d problems", gb.n);
-  bool any_ones = false;
-  int start = 0, all_tiles = 0;
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
-    any_ones = any_ones || p.aug_ones != 0;
     HMP_CHECK_ARG(!p.aug_ones || (p.trans_a && !p.trans_b && p.N == p.n_real + 1), "gemm_x3: the ones column belongs to the TN form with N = n_real + 1");
-    all_tiles += cdiv(p.M, X3_ROWS) * cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, X3_ROWS);
   }
-  for (int i = 0; i < gb.n; ++i) {
-    GemmProblem& p = gb.p[i];
-    p.tiles_m = cdiv(p.M, X3_ROWS);
-    p.tiles_n = cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, X3_ROWS);  // the ones column rides in the first column tile
-    const int tiles = p.tiles_m * p.tiles_n;
-    int ks = 1;
-    if (want_split && tiles > 0) {  // aim at ~4 workgroups per CU over the whole launch; every slab gets at least one K stage
-      ks = 1024 / (all_tiles > 0 ? all_tiles : 1);
-      const int max_by_k = cdiv(p.K, X3_BK);
-      if (ks > max_by_k) ks = max_by_k;
-      if (ks > max_slabs) ks = max_slabs;
-      if (ks < 1) ks = 1;
-    }
-    int kchunk = cdiv(cdiv(p.K, ks), X3_BK) * X3_BK;
-    if (kchunk < X3_BK) kchunk = X3_BK;
-    ks = p.K > 0 ? cdiv(p.K, kchunk) : 1;
-    p.ksplit = ks;
-    p.kchunk = kchunk;
-    p.tile_start = start;
-    start += tiles * ks;
-  }
-  gb.total_tiles = start;
-  if (start == 0) return HMP_OK;
-  int form = -1;
-  for (int i = 0; i < gb.n; ++i) {
-    const GemmProblem& p = gb.p[i];
-    const int f = (!p.trans_a && p.trans_b) ? 0 : (!p.trans_a && !p.trans_b) ? 1 : (p.trans_a && !p.trans_b) ? 2 : 3;
-    form = (form == -1 || form == f) ? f : 3;
-  }
-#define X3_LAUNCH(ONES_, FORM_) hipLaunchKernelGGL((gemm_x3_kernel<ONES_, FORM_>), dim3(start), dim3(X3_NT), 0, st, gb)
-  if (any_ones) {
-    if (form == 2) X3_LAUNCH(true, 2);
-    else X3_LAUNCH(true, 3);
-  } else {
-    switch (form) {
-      case 0: X3_LAUNCH(false, 0); break;
-      case 1: X3_LAUNCH(false, 1); break;
-      case 2: X3_LAUNCH(false, 2); break;
-      default: X3_LAUNCH(false, 3); break;
-    }
-  }
-#undef X3_LAUNCH
-  HMP_LAUNCH_CHECK();
-  return HMP_OK;
+  return x3_launch_cfg<X3Small>(gb, want_split, max_slabs, st);
 }
 
 }  // namespace hmp
