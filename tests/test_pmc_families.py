@@ -59,3 +59,12 @@ def test_a_batch_2048_line_does_not_read_the_batch_32_file():
     assert p32 and "batch" not in os.path.basename(p32)
     assert p2048 and os.path.basename(p2048).endswith("_batch2048.json")
     assert pf.pick_pmc_file(PROF, 2, 77, 32) is None
+
+
+def test_split_kernel_instances_map_by_their_form_argument():
+    """gemm_x3_kernel<tile configuration, ONES, FORM>: the configuration is a template of its own, so FORM is read as the LAST argument"""
+    k = kernels("r03_z_pmc_cfg2_batch2048.json")
+    fam = {name: pf.kernel_family(name) for name in k if "gemm_x3_kernel" in name}
+    assert sorted(fam.values()) == ["gemm_bwd", "gemm_fwd"], fam
+    for name, f in fam.items():
+        assert name.split(">(")[0].rstrip().endswith("0") == (f == "gemm_fwd"), name

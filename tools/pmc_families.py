@@ -60,9 +60,9 @@ def kernel_family(name: str) -> Optional[str]:
     a = _template_args(name, "gemm_bf16_kernel")
     if a is not None:
         return "gemm_fwd" if a[-1] == "0" else "gemm_bwd"
-    a = _template_args(name, "gemm_x3_kernel")  # <ONES, FORM>
-    if a is not None:
-        return "gemm_fwd" if a[-1] == "0" else "gemm_bwd"
+    m = re.search(r"\bgemm_x3_kernel<.*,\s*(\d)>\s*\(", name)  # <tile configuration (itself a template), ONES, FORM>
+    if m:
+        return "gemm_fwd" if m.group(1) == "0" else "gemm_bwd"
     for fam, pat in _SIMPLE:
         if re.search(pat, name):
             return fam
