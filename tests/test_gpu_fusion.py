@@ -325,7 +325,7 @@ def test_bf16_mode_activation_storage_is_bit_identical(n_obj, n_rooms, monkeypat
 
 
 @pytest.mark.parametrize("n_obj,n_rooms,shuffle", [(40000, 400, False), (140000, 1400, False), (40000, 400, True)])
-def test_lds_windowed_aggregation_is_bit_identical(n_obj, n_rooms, shuffle, monkeypatch):
+def test_lds_windowed_aggregation_against_plain_kernels(n_obj, n_rooms, shuffle, monkeypatch):
     """bf16 mode, 256-wide layers, >= 16384 rows: persistent workgroups keep a sliding ring of source rows in LDS and serve
     in-window neighbours from there (agg_fwd_win_kernel / agg_bwd_win_kernel).  Same sums in the same edge order: logits and
     every gradient are BIT-identical to the plain one-wave-per-row kernels (HMP_AGG_WIN=0), also when the numbering has no
@@ -369,6 +369,17 @@ def test_lds_windowed_aggregation_is_bit_identical(n_obj, n_rooms, shuffle, monk
     for k in grads:
         assert torch.equal(grads[k], gref[k]), k
     assert net.native().read_state()[1] == 0
+    if os.environ.get("HMP_TEST_EXPERIMENTS") == "1":
+        # make EXPERIMENTS=1 builds: the forward window sum on the matrix pipe (agg_fwd_mm_kernel, HMP_AGG_MM=1) is another association of
+        # the same fp32 sums, so stored activations move by a bf16 ulp here and there; this bounds its distance to the edge-ordered form
+        # (also for the shuffled graph, where nearly every edge takes the far-edge path and its overflow walk)
+        monkeypatch.setenv("HMP_AGG_MM", "1")
+        out2, grads2 = fwd_bwd()
+        assert net.native().read_state()[1] == 0
+        # (no inequality check: sums of <= 20 bf16 numbers are usually EXACT in fp32, whatever the order -- the two forms often agree bit for bit)
+        assert (out2 - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+        for k in grads2:
+            assert (grads2[k] - gref[k]).norm().item() <= 1e-2 * gref[k].norm().item() + 1e-12, k
 
 
 @pytest.mark.parametrize("hidden", [64, 256])
