@@ -1631,68 +1631,54 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
 
 #ifdef HMP_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (make EXPERIMENTS=1, HMP_AGG_MM=1; correct -- tests/test_gpu_fusion.py runs it against the per-edge kernels -- and SLOWER:
-// 1.47 ms per launch against 1.12 ms, profiles/r03_n_matrix_pipe_window_sum.md).  Round 3: the window sum on the MATRIX pipe (agg_fwd_mm_kernel).  The per-edge window kernel above spends a row of a wave on ~750
-// instructions and waits (profiles/r03_k_window_kernels.md); here the in-window edges of a chunk never become loads at all:
-//     S[64 rows, 256] = C[64 rows, 192 slots] . Ring[192 slots, 256],      C[i, s] = number of edges (ring row s) -> (row i)
-// C is a bf16 COUNT matrix in LDS (small integers: exact), built with one fire-and-forget ds_pk_add_bf16 per in-window edge; the
-// product runs transposed, D^T = Ring^T . C^T (A fragments by ds_read_b64_tr_b16 from the ring's natural [slot][feature] image,
-// B fragments by ds_read_b128 from C), so that a lane owns ONE destination row and 16 of its features -- 4 groups of 4 consecutive
-// ones -- and the whole epilogue (out-of-window edges, the other edge types, root, bias, mean, activation, dropout, store) runs
-// per lane on 8-byte pieces.  16 waves = 8 feature tiles x 2 row tiles, 12 MFMAs per wave and chunk.
-//   * ring: exactly the window, 192 slots (slot = row mod 192), two 256-byte-row sub-images (features 0..127 / 128..255) with the
-//     16-byte chunks XOR-ed by the row (gemm_bf16_bwd.hip: dw_off) -- conflict-free transposed reads.  The next chunk's 64 rows
-//     wait in registers until every wave has left the MFMA phase (they overwrite slots of the window's lower margin);
-//   * out-of-window edges of the window type (10 % at config 5) and the edges of the other types (rooms -> objects): the lane
-//     walks its row's id list, keeps up to 4 far ids, and requests their pieces BEFORE the count build; a buffer load whose offset
-//     lies beyond the records returns 0 without a memory access, so lanes without a far edge cost nothing and nothing branches
-//     around a load.  More than 4 far edges, or more than one edge of another type: a second, waited-for pass (rare);
-//   * sums are fp32 in slot order (MFMA) + far edges: another association of the same sum as the edge-ordered kernels -- compared
-//     against the oracle (tests/test_gpu_config5.py) and within fp32 round-off of the per-edge kernel (tests/test_gpu_fusion.py).
-constexpr int MMS = 192;                       // ring slots = the window
-constexpr int MM_SUB = MMS * 256;              // one sub-image: 128 features x 192 slots
-constexpr int MM_RING = 2 * MM_SUB;            // 96 KB
-constexpr int MM_CP = 400;                     // bytes per row of C: 192 counts + pad; 25 x 16 bytes (odd: rows spread over the banks)
-constexpr int MM_CBYTES = WR * MM_CP;          // 25 KB
-constexpr int MM_FARCAP = 8;                   // far ids kept per row (more: walked from the id list)
-constexpr int MM_LDS_FAR = WR * MM_FARCAP * 4 + WR * 4;
-constexpr int MM_LDS = MM_RING + MM_CBYTES + WIN_LDS_IDS + WIN_LDS_RP + MM_LDS_FAR;
-static_assert(MM_LDS <= 160 * 1024 && WM + WR + WM == MMS && (MM_RING + MM_CBYTES + WIN_LDS_IDS) % 16 == 0, "LDS budget / window = ring / aligned far lists");
-static_assert(WIN_WAVES == 16, "8 feature tiles x 2 row tiles");
-typedef __bf16 mm_bf16x8 __attribute__((ext_vector_type(8)));
-typedef short mm_s16x4 __attribute__((ext_vector_type(4)));
-typedef float mm_f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) unsigned char* mm_lds_ptr_t;
-__device__ __forceinline__ uint32_t mm_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(mm_lds_ptr_t)p; }
-__device__ __forceinline__ int mm_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
-__device__ __forceinline__ mm_s16x4 mm_read_tr(uint32_t addr) {
-  mm_s16x4 r;
+// EXPERIMENT (make EXPERIMENTS=1, HMP_AGG_W4=1; correct -- tests/test_gpu_fusion.py, test_gpu_config5.py pass with it -- and SLOWER than
+// the per-edge kernel: 1.8 against 1.12 ms per launch; stamps and the two earlier forms: profiles/r03_n_matrix_pipe_window_sum.md).
+// Round 3, third form of the matrix-pipe window sum (agg_fwd_w4_kernel): the per-edge kernel's ROW-PER-WAVE layout for everything per
+// row, the product only for the in-window sum -- without any hand-over between waves.  v_mfma_f32_4x4x4_16b_bf16 multiplies 16
+// independent 4 x 4 x 4 blocks per wave; with the SAME A block in all of them (the count-matrix rows of the wave's 4 destination
+// rows: lane 4 b + i supplies row i) and B block b = 4 ring slots x features 4 b .. 4 b + 3 (one ds_read_b64_tr_b16 per lane from the
+// ring's natural [slot][feature] image), one instruction adds 4 slots into 4 rows x 64 features: lane l = feature 64 c + l of call c,
+// register i = row i (tools/microbench/mfma4_layout.hip checks this layout on the hardware).  48 k steps x 4 calls per chunk and
+// wave cover the window; only k steps in which one of the wave's rows has an edge are executed (a 48-bit mask built with the counts).
+// A lane then owns features l, 64 + l, 128 + l, 192 + l of each row: every row access is a 128-byte run per 64-feature slice.
+// Out-of-window edges (a per-row far table built with the counts) and the other edge types are requested per slice for all 4 rows.
+// LDS: ring 96 KB (192 slots = the window; the next chunk's rows wait in registers) + counts 25 KB + ids / extents / far table.
+// Sums: slot order + far edges in edge order (fp32; another association).
+constexpr int W4S = 192, W4_SUB = W4S * 256, W4_RING = 2 * W4_SUB, W4_CP = 400, W4_CBYTES = WR * W4_CP, W4_FARCAP = 8;
+constexpr int W4_LDS_FAR = WR * W4_FARCAP * 4 + WR * 4 + WIN_WAVES * 8;  // far ids, far counts, k-step masks
+constexpr int W4_LDS = W4_RING + W4_CBYTES + WIN_LDS_IDS + W4_LDS_FAR + WIN_LDS_RP;
+static_assert(W4_LDS <= 160 * 1024 && WM + WR + WM == W4S && WG == 4 && (W4_RING + W4_CBYTES + WIN_LDS_IDS) % 16 == 0, "LDS budget / window = ring / 4 rows per wave");
+typedef short w4_s16x4 __attribute__((ext_vector_type(4)));
+typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char* w4_lds_ptr_t;
+__device__ __forceinline__ uint32_t w4_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(w4_lds_ptr_t)p; }
+__device__ __forceinline__ int w4_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ w4_s16x4 w4_read_tr(uint32_t addr) {
+  w4_s16x4 r;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
   return r;
 }
-// LDS operations done, then the barrier -- WITHOUT draining the vector-memory counter: the far / root / staging loads stay in flight
-__device__ __forceinline__ void mm_barrier() {
+__device__ __forceinline__ void w4_barrier() {  // LDS operations done, then the barrier; vector-memory requests stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ int mm_slot(int r) {
-  int s = r % MMS;
-  return s < 0 ? s + MMS : s;
+__device__ __forceinline__ int w4_slot(int r) {
+  int s = r % W4S;
+  return s < 0 ? s + W4S : s;
 }
-// 16-byte piece `piece` (0..31) of ring row `slot`
-__device__ __forceinline__ unsigned char* mm_ring_at(unsigned char* ring, int slot, int piece) {
-  return ring + (piece >> 4) * MM_SUB + mm_off(slot, piece & 15);
+__device__ __forceinline__ unsigned char* w4_ring_at(unsigned char* ring, int slot, int piece) {  // 16-byte piece (0..31) of a ring row
+  return ring + (piece >> 4) * W4_SUB + w4_off(slot, piece & 15);
 }
-
 template <bool HB>
-__global__ __launch_bounds__(WIN_THREADS) void agg_fwd_mm_kernel(const WinFwd a) {
+__global__ __launch_bounds__(WIN_THREADS) void agg_fwd_w4_kernel(const WinFwd a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
   unsigned char* ring = wlds;
-  unsigned char* cmat = wlds + MM_RING;
-  int* idbuf = reinterpret_cast<int*>(wlds + MM_RING + MM_CBYTES);                 // [2][WIDCAP]
-  int* farid = reinterpret_cast<int*>(wlds + MM_RING + MM_CBYTES + WIN_LDS_IDS);   // [WR][MM_FARCAP] (16-byte aligned rows)
-  int* farcnt = farid + WR * MM_FARCAP;                                            // [WR]
-  int* rpbuf = farcnt + WR;                                                        // [3][AGG_MAX_IN][WRP]
+  unsigned char* cmat = wlds + W4_RING;
+  int* idbuf = reinterpret_cast<int*>(wlds + W4_RING + W4_CBYTES);                 // [2][WIDCAP]
+  int* farid = reinterpret_cast<int*>(wlds + W4_RING + W4_CBYTES + WIN_LDS_IDS);   // [WR][W4_FARCAP]
+  int* farcnt = farid + WR * W4_FARCAP;                                            // [WR]
+  unsigned long long* kmask = reinterpret_cast<unsigned long long*>(farcnt + WR);  // [WIN_WAVES]: k steps (of 4 slots) with an edge into the wave's rows
+  int* rpbuf = reinterpret_cast<int*>(kmask + WIN_WAVES);                          // [3][AGG_MAX_IN][WRP]
   const AggDst& D = a.d;
   const int n_rows = D.n_rows, nq = D.n_in;
   const int c_begin = (int)blockIdx.x * a.chunks_per_block;
@@ -1702,17 +1688,19 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_mm_kernel(const WinFwd a)
   const int WQ = D.win_in;
   const AggIn& IW = D.in[WQ];
   const uint16_t* zwin = reinterpret_cast<const uint16_t*>(IW.z) + IW.coff;
-  const int ft = wave & 7, dt = wave >> 3;  // this wave's feature tile (32 features) and row tile (32 rows)
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int fcol = ft * 32 + 4 * hh;        // the lane's feature groups: fcol + 8 g .. + 3, g = 0..3
   DropCfg dcfg = D.drop;
   if (D.drop_on) dcfg = drop_resolve(D.drop);
+  const uint32_t t16 = dcfg.thresh >> 16;
+  float biasv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (D.bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) biasv[c] = D.bias[64 * c + lane];
+  }
   auto zero_c = [&]() {
-    for (int p = threadIdx.x; p < MM_CBYTES / 16; p += WIN_THREADS) *reinterpret_cast<uint4*>(cmat + p * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int p = threadIdx.x; p < W4_CBYTES / 16; p += WIN_THREADS) *reinterpret_cast<uint4*>(cmat + p * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if ((int)threadIdx.x < WIN_WAVES) kmask[threadIdx.x] = 0ull;
   };
-
-  // ---- prologue: extents of chunks c_begin, c_begin + 1; ids of c_begin; the whole first window (rows outside the matrix: zeros --
-  // every slot takes part in the product, so it must hold finite numbers) --------------------------------------------------------
+  // ---- prologue ------------------------------------------------------------------------------------------------------------------------
   {
     const int r0 = win_load_rp(D, c_begin, a.n_chunks), r1 = win_load_rp(D, c_begin + 1, a.n_chunks);
     if ((int)threadIdx.x < nq * WRP) {
@@ -1720,11 +1708,11 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_mm_kernel(const WinFwd a)
       rpbuf[((c_begin + 1) % 3) * AGG_MAX_IN * WRP + threadIdx.x] = r1;
     }
     const int lo = c_begin * WR - WM;
-    for (int p = threadIdx.x; p < MMS * 32; p += WIN_THREADS) {
+    for (int p = threadIdx.x; p < W4S * 32; p += WIN_THREADS) {  // the whole first window; rows outside the matrix: zeros (every slot is multiplied)
       const int r = lo + (p >> 5), piece = p & 31;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (r >= 0 && r < n_rows) v = *reinterpret_cast<const uint4*>(zwin + (int64_t)r * IW.ldz + piece * 8);
-      *reinterpret_cast<uint4*>(mm_ring_at(ring, mm_slot(r), piece)) = v;
+      *reinterpret_cast<uint4*>(w4_ring_at(ring, w4_slot(r), piece)) = v;
     }
     zero_c();
     __syncthreads();
@@ -1745,79 +1733,7 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_mm_kernel(const WinFwd a)
     const int* rp = rpbuf + (ch % 3) * AGG_MAX_IN * WRP;
     const int* idc = idbuf + (ch & 1) * WIDCAP;
     const bool next = ch + 1 < c_end;
-    int off[AGG_MAX_IN], eb[AGG_MAX_IN];
-    const bool fits = win_offsets(rp, nq, off, eb);
-    const int wlo = max(r_c - WM, 0), whi = min(r_c + WR + WM, n_rows);  // rows the ring holds now
-    const int offW = sel_q(off, WQ) - sel_q(eb, WQ);
-    // ---- count matrix + far table: the 16 threads (i, k) of row i take its edges k, k + 16, ..; an in-window edge adds 1 to C[i][slot],
-    // an out-of-window one is appended to the row's far list (its position = far edges before it: a ballot, no atomics -- the far
-    // sums keep their edge order, run-to-run identical) ---------------------------------------------------------------------------
-    {
-      const int i = (int)threadIdx.x >> 4, k0 = threadIdx.x & 15;
-      const int b = rp[WQ * WRP + i], e = rp[WQ * WRP + i + 1];
-      int nfar = 0;
-      for (int base = b;; base += 16) {
-        if (!__any(base < e)) break;  // wave-uniform (the four rows of a wave may differ in length)
-        const int p = base + k0;
-        const bool act = p < e;
-        const int id = act ? (fits ? idc[offW + p] : IW.col[p]) : 0;
-        const bool inw = act && id >= wlo && id < whi;
-        const bool far = act && !inw;
-        if (inw) {
-          const int sl = id % MMS;
-          asm volatile("ds_pk_add_bf16 %0, %1" ::"v"(mm_lds_addr(cmat + i * MM_CP + (sl >> 1) * 4)), "v"((sl & 1) ? 0x3f800000u : 0x00003f80u) : "memory");
-        }
-        const unsigned long long fb = __ballot(far);
-        const unsigned grp = (unsigned)(fb >> (lane & 48)) & 0xffffu;  // the far flags of this row's 16 threads
-        const int pos = nfar + __popc(grp & ((1u << k0) - 1u));
-        if (far && pos < MM_FARCAP) farid[i * MM_FARCAP + pos] = id;
-        nfar += __popc(grp);
-      }
-      if (k0 == 0) farcnt[i] = nfar;
-    }
-    mm_barrier();  // C and the far lists complete
-    KT_ADD(20, kt_0);
-    [[maybe_unused]] const unsigned long long kt_1 = KT_NOW();
-    // ---- the lane's row: every request of the chunk that does not depend on the product, then the requests for the chunks ahead ----
-    const int il = dt * 32 + l31, row = r_c + il;
-    const bool live = row < n_rows;
-    const int rowc = live ? row : n_rows - 1;
-    const int bW = rp[WQ * WRP + il], eW = rp[WQ * WRP + il + 1];
-    const int dW = live ? eW - bW : 0;
-    const int nf = farcnt[il];
-    const int4 fid = *reinterpret_cast<const int4*>(farid + il * MM_FARCAP);
-    const __amdgpu_buffer_rsrc_t rsW = win_rsrc(zwin, (unsigned)IW.n_src * (unsigned)(IW.ldz * 2) - (unsigned)(IW.coff * 2));
-    u32x2 farv[4][4];
-    {
-      const int fi[4] = {fid.x, fid.y, fid.z, fid.w};
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const unsigned vo = f < nf ? (unsigned)fi[f] * (unsigned)(IW.ldz * 2) + (unsigned)(fcol * 2) : WIN_SKIP_OFF;  // beyond the records: 0, no access
-#pragma unroll
-        for (int g = 0; g < 4; ++g) farv[f][g] = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo, 16 * g, 0);
-      }
-    }
-    uint2 rootv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      rootv[g] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(D.zroot) + (int64_t)rowc * D.ldzr + D.roff + fcol + 8 * g);
-    // the first edge of the first other edge type (rooms -> objects: every row has exactly one)
-    const int DQ = (nq > 1) ? (WQ == 0 ? 1 : 0) : -1;  // wave-uniform
-    u32x2 othv[4];
-    {  // (no branch around the loads: without such an edge type the offset lies beyond the records)
-      const int dq = DQ >= 0 ? DQ : WQ;
-      const AggIn& I = D.in[dq];
-      const int bD = rp[dq * WRP + il];
-      const int eD = (live && DQ >= 0) ? rp[dq * WRP + il + 1] : bD;
-      const int id0 = eD > bD ? (fits ? idc[sel_q(off, dq) - sel_q(eb, dq) + bD] : I.col[bD]) : 0;
-      const uint16_t* zq = reinterpret_cast<const uint16_t*>(I.z) + I.coff;
-      const __amdgpu_buffer_rsrc_t rs = win_rsrc(zq, (unsigned)I.n_src * (unsigned)(I.ldz * 2) - (unsigned)(I.coff * 2));
-      const unsigned vo = eD > bD ? (unsigned)id0 * (unsigned)(I.ldz * 2) + (unsigned)(fcol * 2) : WIN_SKIP_OFF;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) othv[g] = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 16 * g, 0);
-    }
-    // requests for the chunks ahead, issued LAST: the counter of vector-memory operations retires in order, so the pieces above are
-    // usable while these are still in flight; they go to LDS at the end of the chunk
+    // ---- requests for the chunks ahead --------------------------------------------------------------------------------------------------
     WinStage stg;
     {
       const int nlo = r_c + WR + WM;  // new ring rows of chunk ch + 1: [nlo, nlo + WR)
@@ -1831,159 +1747,192 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_mm_kernel(const WinFwd a)
       win_load_ids(D, rpbuf + ((ch + 1) % 3) * AGG_MAX_IN * WRP, next, stg.ids);
       stg.rp = (ch + 2 < c_end) ? win_load_rp(D, ch + 2, a.n_chunks) : 0;
     }
-    KT_ADD(21, kt_1);
-    [[maybe_unused]] const unsigned long long kt_4 = KT_NOW();
-    // ---- the product: 12 k steps of 16 slots -------------------------------------------------------------------------------------------
-    mm_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int off[AGG_MAX_IN], eb[AGG_MAX_IN];
+    const bool fits = win_offsets(rp, nq, off, eb);
+    const int wlo = max(r_c - WM, 0), whi = min(r_c + WR + WM, n_rows);  // rows the ring holds now
+    const int offW = sel_q(off, WQ) - sel_q(eb, WQ);
+    // ---- counts + far table + k-step masks: the 16 threads (i, k) of row i take its edges k, k + 16, .. -------------------------------
     {
-      const unsigned char* Ai = ring + (ft >> 2) * MM_SUB;
-      const int gi = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-      const int c0 = 4 * (ft & 3) + 2 * (gi & 1) + (pp >> 1);
-      const unsigned char* Bi = cmat + (dt * 32 + l31) * MM_CP + 16 * hh;
-#pragma unroll 4
-      for (int ks = 0; ks < MMS / 16; ++ks) {
-        const int r0 = 16 * ks + 8 * (gi >> 1);
-        union { mm_s16x4 h[2]; mm_bf16x8 v; } ua;
-        ua.h[0] = mm_read_tr(mm_lds_addr(Ai + mm_off(r0 + q, c0) + 8 * (pp & 1)));
-        ua.h[1] = mm_read_tr(mm_lds_addr(Ai + mm_off(r0 + 4 + q, c0) + 8 * (pp & 1)));
-        const mm_bf16x8 bv = *reinterpret_cast<const mm_bf16x8*>(Bi + 32 * ks);
+      const int i = (int)threadIdx.x >> 4, k0 = threadIdx.x & 15;
+      const int b = rp[WQ * WRP + i], e = rp[WQ * WRP + i + 1];
+      int nfar = 0;
+      unsigned long long km = 0ull;
+      for (int base = b;; base += 16) {
+        if (!__any(base < e)) break;  // wave-uniform (the four rows of a wave may differ in length)
+        const int p = base + k0;
+        const bool act = p < e;
+        const int id = act ? (fits ? idc[offW + p] : IW.col[p]) : 0;
+        const bool inw = act && id >= wlo && id < whi;
+        const bool far = act && !inw;
+        if (inw) {
+          const int sl = id % W4S;
+          asm volatile("ds_pk_add_bf16 %0, %1" ::"v"(w4_lds_addr(cmat + i * W4_CP + (sl >> 1) * 4)), "v"((sl & 1) ? 0x3f800000u : 0x00003f80u) : "memory");
+          km |= 1ull << (sl >> 2);
+        }
+        const unsigned long long fb = __ballot(far);
+        const unsigned grp = (unsigned)(fb >> (lane & 48)) & 0xffffu;  // the far flags of this row's 16 threads
+        const int pos = nfar + __popc(grp & ((1u << k0) - 1u));
+        if (far && pos < W4_FARCAP) farid[i * W4_FARCAP + pos] = id;
+        nfar += __popc(grp);
+      }
+      if (k0 == 0) farcnt[i] = nfar;
+      if (km) atomicOr(&kmask[i >> 2], km);  // rows 4 w .. 4 w + 3 belong to wave w (an OR of flags: order-independent)
+    }
+    w4_barrier();  // counts, far table and masks complete
+    KT_ADD(20, kt_0);
+    [[maybe_unused]] const unsigned long long kt_4 = KT_NOW();
+    // ---- the product for the wave's rows 4 w .. 4 w + 3 ---------------------------------------------------------------------------------------
+    w4_f32x4 accm[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accm[c] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      unsigned long long km = kmask[wave];
+      km = ((unsigned long long)(uint32_t)uni((int)(km >> 32)) << 32) | (uint32_t)uni((int)km);
+      const unsigned char* Ai = cmat + (4 * wave + (lane & 3)) * W4_CP;
+      const int q = (lane & 15) >> 2;
+      uint32_t boff[4];  // byte offset of this lane's transposed-read address inside a ring row group, per call c (without the row term)
+      int bch[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int fo = 64 * (c & 1) + 16 * (lane >> 4) + 4 * (lane & 3);  // feature offset inside the sub-image
+        bch[c] = fo >> 3;
+        boff[c] = (c >> 1) * W4_SUB + 8 * ((fo >> 2) & 1);
+      }
+      while (km) {  // wave-uniform
+        const int k4 = __builtin_ctzll(km);
+        km &= km - 1ull;
+        const int row = 4 * k4 + q;
+        const uint2 araw = *reinterpret_cast<const uint2*>(Ai + 8 * k4);
+        w4_s16x4 bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[c] = w4_read_tr(w4_lds_addr(ring + boff[c] + w4_off(row, bch[c])));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, bv, acc, 0, 0, 0);
+        union { uint2 u; w4_s16x4 v; } ua;
+        ua.u = araw;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accm[c] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ua.v, bv[c], accm[c], 0, 0, 0);
       }
     }
-    mm_barrier();  // every wave has left the ring and C
+    w4_barrier();  // every wave has left the ring and C
     KT_ADD(24, kt_4);
-    [[maybe_unused]] const unsigned long long kt_6 = KT_NOW();
-    // ---- epilogue, per lane: row `row`, features fcol + 8 g + (0..3) -------------------------------------------------------------------
-    Acc<4> sumW[4];
+    [[maybe_unused]] const unsigned long long kt_7 = KT_NOW();
+    // ---- the wave's 4 rows x 256 features, one 64-feature slice (MFMA call c) at a time: per slice ALL the rows' requests -- root, the
+    // first three far edges, the first edge of the other edge type -- are issued together (20 loads of 128 contiguous bytes), then
+    // summed, finished and stored.  (Row by row -- the per-edge kernel's order -- every row waited for its own far row and then for its
+    // rooms -> objects row with nothing else to do: 13 us of a 22 us chunk.) -----------------------------------------------------------------
+    const int DQ = (nq > 1) ? (WQ == 0 ? 1 : 0) : -1;  // first other edge type; further types (and further edges of this one) are walked
+    const AggIn& ID = D.in[DQ >= 0 ? DQ : WQ];
+    const uint16_t* zoth = reinterpret_cast<const uint16_t*>(ID.z) + ID.coff;
+    const __amdgpu_buffer_rsrc_t rsW = win_rsrc(zwin, (unsigned)IW.n_src * (unsigned)(IW.ldz * 2) - (unsigned)(IW.coff * 2));
+    const __amdgpu_buffer_rsrc_t rsD = win_rsrc(zoth, (unsigned)ID.n_src * (unsigned)(ID.ldz * 2) - (unsigned)(ID.coff * 2));
+    const int offD = DQ >= 0 ? sel_q(off, DQ) - sel_q(eb, DQ) : 0;
+    int rowg[4], nfg[4], dWg[4], bDg[4], dDg[4], f0g[4], f1g[4], f2g[4], d0g[4];  // wave-uniform per row
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      sumW[g].v = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        Acc<4> w;
-        widen_bf16x4(w, make_uint2(farv[f][g][0], farv[f][g][1]));
-        sumW[g].add(w);
-      }
+      const int il = 4 * wave + g;
+      rowg[g] = r_c + il;
+      const bool live = rowg[g] < n_rows;
+      dWg[g] = live ? uni(rp[WQ * WRP + il + 1]) - uni(rp[WQ * WRP + il]) : 0;
+      nfg[g] = live ? uni(farcnt[il]) : 0;
+      f0g[g] = uni(farid[il * W4_FARCAP + 0]);
+      f1g[g] = uni(farid[il * W4_FARCAP + 1]);
+      f2g[g] = uni(farid[il * W4_FARCAP + 2]);
+      bDg[g] = DQ >= 0 ? uni(rp[DQ * WRP + il]) : 0;
+      dDg[g] = (live && DQ >= 0) ? uni(rp[DQ * WRP + il + 1]) - bDg[g] : 0;
+      d0g[g] = dDg[g] > 0 ? uni(fits ? idc[offD + bDg[g]] : ID.col[bDg[g]]) : 0;
     }
-    if (__any(nf > 4)) {  // wave-uniform: a second round for far edges 4 .. 7 of the lists
-      const int4 fid2 = *reinterpret_cast<const int4*>(farid + il * MM_FARCAP + 4);
-      const int fi[4] = {fid2.x, fid2.y, fid2.z, fid2.w};
-      u32x2 fv[4][4];
+    const int ldW2 = IW.ldz * 2, ldD2 = ID.ldz * 2;
+    auto bf = [](uint32_t v) { return __uint_as_float(v << 16); };
+    auto slice = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const unsigned vo = (unsigned)(lane * 2 + 128 * c);
+      uint32_t rootv[4], farv[4][3], othv[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const unsigned vo = f + 4 < nf ? (unsigned)fi[f] * (unsigned)(IW.ldz * 2) + (unsigned)(fcol * 2) : WIN_SKIP_OFF;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) fv[f][g] = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo, 16 * g, 0);
+      for (int g = 0; g < 4; ++g) {
+        const int rowc = min(rowg[g], n_rows - 1);
+        rootv[g] = reinterpret_cast<const uint16_t*>(D.zroot)[(int64_t)rowc * D.ldzr + D.roff + 64 * c + lane];
+        farv[g][0] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsW, nfg[g] > 0 ? vo : WIN_SKIP_OFF, f0g[g] * ldW2, 0);
+        farv[g][1] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsW, nfg[g] > 1 ? vo : WIN_SKIP_OFF, f1g[g] * ldW2, 0);
+        farv[g][2] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsW, nfg[g] > 2 ? vo : WIN_SKIP_OFF, f2g[g] * ldW2, 0);
+        othv[g] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsD, dDg[g] > 0 ? vo : WIN_SKIP_OFF, d0g[g] * ldD2, 0);
       }
+      // dropout decisions of quad 16 c + (lane >> 2) of the four rows: quad lane j computes row j's pair, the four lanes exchange them
+      uint32_t ha = 0u, hb = 0u;
+      if (D.drop_on) {
+        const int rsel = (lane & 3) == 0 ? rowg[0] : ((lane & 3) == 1 ? rowg[1] : ((lane & 3) == 2 ? rowg[2] : rowg[3]));
+        drop_pair(dcfg, (uint32_t)min(rsel, n_rows - 1) * (uint32_t)(D.ldo >> 2) + (uint32_t)(16 * c + (lane >> 2)), ha, hb);
+      }
+      uint32_t pa[4], pb[4];
+      pa[0] = __builtin_amdgcn_mov_dpp((int)ha, 0x00, 0xf, 0xf, true); pb[0] = __builtin_amdgcn_mov_dpp((int)hb, 0x00, 0xf, 0xf, true);
+      pa[1] = __builtin_amdgcn_mov_dpp((int)ha, 0x55, 0xf, 0xf, true); pb[1] = __builtin_amdgcn_mov_dpp((int)hb, 0x55, 0xf, 0xf, true);
+      pa[2] = __builtin_amdgcn_mov_dpp((int)ha, 0xaa, 0xf, 0xf, true); pb[2] = __builtin_amdgcn_mov_dpp((int)hb, 0xaa, 0xf, 0xf, true);
+      pa[3] = __builtin_amdgcn_mov_dpp((int)ha, 0xff, 0xf, 0xf, true); pb[3] = __builtin_amdgcn_mov_dpp((int)hb, 0xff, 0xf, 0xf, true);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          Acc<4> w;
-          widen_bf16x4(w, make_uint2(fv[f][g][0], fv[f][g][1]));
-          sumW[g].add(w);
-        }
-    }
-    if (__any(nf > MM_FARCAP)) {  // wave-uniform, rare (a graph without locality): the far edges beyond the table, walked one waited-for edge at a time
-      int seen = 0;
-      for (int k = 0;; ++k) {
-        const bool act = k < dW;
-        if (!__any(act)) break;
-        const int id = act ? (fits ? idc[offW + bW + k] : IW.col[bW + k]) : 0;
-        const bool far = act && !(id >= wlo && id < whi);
-        const bool take = far && seen >= MM_FARCAP;
-        seen += far ? 1 : 0;
-        if (__any(take)) {
-          const unsigned vo = take ? (unsigned)id * (unsigned)(IW.ldz * 2) + (unsigned)(fcol * 2) : WIN_SKIP_OFF;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo, 16 * g, 0);
-            Acc<4> w;
-            widen_bf16x4(w, make_uint2(v[0], v[1]));
-            sumW[g].add(w);
+      for (int g = 0; g < 4; ++g) {
+        if (rowg[g] >= n_rows) continue;  // wave-uniform
+        const int il = 4 * wave + g;
+        float sw = accm[c][g] + bf(farv[g][0]);
+        sw += bf(farv[g][1]);
+        sw += bf(farv[g][2]);
+        if (nfg[g] > 3) {  // further far edges: table entries 3 .. 7, then (a graph without locality) the rest of the row's list
+          for (int jf = 3; jf < min(nfg[g], W4_FARCAP); ++jf)
+            sw += bf((uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsW, vo, uni(farid[il * W4_FARCAP + jf]) * ldW2, 0));
+          if (nfg[g] > W4_FARCAP) {
+            const int b = uni(rp[WQ * WRP + il]);
+            int seen = 0;
+            for (int p = 0; p < dWg[g]; ++p) {
+              const int id = uni(fits ? idc[offW + b + p] : IW.col[b + p]);
+              if (id >= wlo && id < whi) continue;
+              if (seen++ < W4_FARCAP) continue;
+              sw += bf((uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsW, vo, id * ldW2, 0));
+            }
           }
         }
-      }
-    }
-    KT_ADD(26, kt_6);
-    [[maybe_unused]] const unsigned long long kt_7 = KT_NOW();
-    Acc<4> tot[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      widen_bf16x4(tot[g], rootv[g]);
-      if (D.bias) {
-        Acc<4> bq;
-        bq.load(D.bias + fcol + 8 * g);
-        tot[g].add(bq);
-      }
-      if (dW > 0) tot[g].add_div(sumW[g], a.mean ? (float)dW : 1.f);
-    }
-    // the other edge types, in order: the first edge of the first one is already here, the rest is walked (one waited-for edge at a time)
-#pragma unroll 1
-    for (int q = 0; q < nq; ++q) {
-      if (q == WQ) continue;
-      const AggIn& I = D.in[q];
-      const int b = rp[q * WRP + il];
-      const int e = live ? rp[q * WRP + il + 1] : b;
-      const uint16_t* zq = reinterpret_cast<const uint16_t*>(I.z) + I.coff;
-      const __amdgpu_buffer_rsrc_t rs = win_rsrc(zq, (unsigned)I.n_src * (unsigned)(I.ldz * 2) - (unsigned)(I.coff * 2));
-      const int offq = sel_q(off, q) - sel_q(eb, q);
-      Acc<4> sq[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) sq[g].zero();
-      int k = 0;
-      if (q == DQ) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) widen_bf16x4(sq[g], make_uint2(othv[g][0], othv[g][1]));
-        k = 1;
-      }
-      for (;; ++k) {
-        const bool act = b + k < e;
-        if (!__any(act)) break;
-        const int id = act ? (fits ? idc[offq + b + k] : I.col[b + k]) : 0;
-        const unsigned vo = act ? (unsigned)id * (unsigned)(I.ldz * 2) + (unsigned)(fcol * 2) : WIN_SKIP_OFF;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 16 * g, 0);
-          Acc<4> w;
-          widen_bf16x4(w, make_uint2(v[0], v[1]));
-          sq[g].add(w);
+        float v = biasv[c] + bf(rootv[g]);
+        if (dWg[g] > 0) v = fmaf(sw, a.mean ? 1.0f / (float)dWg[g] : 1.f, v);
+        if (dDg[g] > 0) {
+          float sd = bf(othv[g]);
+          for (int p = 1; p < dDg[g]; ++p)  // (further edges of the other type: one waited-for row at a time)
+            sd += bf((uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsD, vo, uni(fits ? idc[offD + bDg[g] + p] : ID.col[bDg[g] + p]) * ldD2, 0));
+          v = fmaf(sd, a.mean ? 1.0f / (float)dDg[g] : 1.f, v);
         }
-      }
-      if (e > b) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) tot[g].add_div(sq[g], a.mean ? (float)(e - b) : 1.f);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c0 = fcol + 8 * g;
-      bool keep[4] = {true, true, true, true};
-      if (D.drop_on) drop_keep4(dcfg, (uint32_t)rowc * (uint32_t)(D.ldo >> 2) + (uint32_t)(c0 >> 2), keep);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {  // as agg_row's epilogue
-        float v = tot[g].at(i);
+        for (int q = 0; q < nq; ++q) {  // a third, fourth .. edge type: walked
+          if (q == WQ || q == DQ) continue;
+          const AggIn& I = D.in[q];
+          const int b = uni(rp[q * WRP + il]), e = uni(rp[q * WRP + il + 1]);
+          if (e == b) continue;
+          const uint16_t* zq = reinterpret_cast<const uint16_t*>(I.z) + I.coff;
+          const int offq = sel_q(off, q) - sel_q(eb, q);
+          float sq = 0.f;
+          for (int p = b; p < e; ++p) sq += bf((uint32_t)zq[(int64_t)uni(fits ? idc[offq + p] : I.col[p]) * I.ldz + 64 * c + lane]);
+          v = fmaf(sq, a.mean ? 1.0f / (float)(e - b) : 1.f, v);
+        }
         if (D.act == HMP_ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (D.act == HMP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
-        if (D.drop_on) v = keep[i] ? (v * D.drop.scale + 0.0f) : -0.0f;
-        tot[g].at(i) = v;
+        if (D.drop_on) {
+          const uint32_t word = (lane & 2) ? pb[g] : pa[g];
+          const uint32_t draw = (lane & 1) ? (word >> 16) : (word & 0xffffu);
+          v = draw >= t16 ? (v * D.drop.scale + 0.0f) : -0.0f;
+        }
+        if constexpr (HB) reinterpret_cast<__bf16*>(D.out)[(int64_t)rowg[g] * D.ldo + 64 * c + lane] = (__bf16)v;
+        else D.out[(int64_t)rowg[g] * D.ldo + 64 * c + lane] = v;
       }
-      if (live) store_z<HB>(tot[g], D.out, (int64_t)row * D.ldo + c0);
-    }
+    };
+    slice(std::integral_constant<int, 0>());
+    slice(std::integral_constant<int, 1>());
+    slice(std::integral_constant<int, 2>());
+    slice(std::integral_constant<int, 3>());
     KT_ADD(27, kt_7);
     [[maybe_unused]] const unsigned long long kt_5 = KT_NOW();
-    // ---- what the requests brought goes to LDS; C is cleared for the next chunk ------------------------------------------------------
+    // ---- what the requests brought goes to LDS; the counts are cleared for the next chunk -----------------------------------------------
     if (next) {
       const int nlo = r_c + WR + WM;
 #pragma unroll
       for (int it = 0; it < (WR * 32) / WIN_THREADS; ++it) {
         const int p = (int)threadIdx.x + it * WIN_THREADS;
         const int r = nlo + (p >> 5), piece = p & 31;
-        *reinterpret_cast<uint4*>(mm_ring_at(ring, mm_slot(r), piece)) = stg.rows[it];  // (rows past the matrix: zeros)
+        *reinterpret_cast<uint4*>(w4_ring_at(ring, w4_slot(r), piece)) = stg.rows[it];  // (rows past the matrix: zeros)
       }
 #pragma unroll
       for (int it = 0; it < (WIDCAP + WIN_THREADS - 1) / WIN_THREADS; ++it) {
@@ -1995,7 +1944,7 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_mm_kernel(const WinFwd a)
     }
     KT_ADD(25, kt_5);
     [[maybe_unused]] const unsigned long long kt_8 = KT_NOW();
-    mm_barrier();  // the next chunk's ring rows, ids, extents and the cleared C are in place
+    w4_barrier();
     KT_ADD(28, kt_8);
     KT_ADD(29, kt_0);
   }
@@ -2225,9 +2174,9 @@ static bool agg_win_enabled() {
   return !(v && v[0] == '0');
 }
 #ifdef HMP_EXPERIMENTS
-// experiment builds, HMP_AGG_MM=1: the forward window sum on the matrix pipe (agg_fwd_mm_kernel) instead of edge by edge
-static bool agg_mm_enabled() {
-  const char* v = getenv("HMP_AGG_MM");
+// experiment builds, HMP_AGG_W4=1: the forward in-window sum by 4x4x4 MFMAs over a count matrix (agg_fwd_w4_kernel) instead of edge by edge
+static bool agg_w4_enabled() {
+  const char* v = getenv("HMP_AGG_W4");
   return v && v[0] == '1';
 }
 #endif
@@ -2324,15 +2273,15 @@ int agg_fwd_launch(AggArgs& a, hipStream_t st) {
 #endif
         const int grid = agg_win_grid(w.n_chunks, w.chunks_per_block);
 #ifdef HMP_EXPERIMENTS
-        if (agg_mm_enabled()) {  // the window sum on the matrix pipe
-          static bool mm_attr_done = false;
-          if (!mm_attr_done) {
-            HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_fwd_mm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS));
-            HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_fwd_mm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS));
-            mm_attr_done = true;
+        if (agg_w4_enabled()) {  // the in-window sum on the matrix pipe, row-per-wave layout
+          static bool w4_attr_done = false;
+          if (!w4_attr_done) {
+            HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_fwd_w4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS));
+            HMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_fwd_w4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS));
+            w4_attr_done = true;
           }
-          if (a.hb16) hipLaunchKernelGGL((agg_fwd_mm_kernel<true>), dim3(grid), dim3(WIN_THREADS), MM_LDS, st, w);
-          else hipLaunchKernelGGL((agg_fwd_mm_kernel<false>), dim3(grid), dim3(WIN_THREADS), MM_LDS, st, w);
+          if (a.hb16) hipLaunchKernelGGL((agg_fwd_w4_kernel<true>), dim3(grid), dim3(WIN_THREADS), W4_LDS, st, w);
+          else hipLaunchKernelGGL((agg_fwd_w4_kernel<false>), dim3(grid), dim3(WIN_THREADS), W4_LDS, st, w);
         } else
 #endif
         if (a.hb16) hipLaunchKernelGGL((agg_fwd_win_kernel<true>), dim3(grid), dim3(WIN_THREADS), WIN_LDS_FWD, st, w);

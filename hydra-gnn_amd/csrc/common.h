@@ -213,12 +213,18 @@ __host__ __device__ inline uint32_t drop_thresh(float p) {
   return (uint32_t)t;
 }
 
-// keep flags for the 4 consecutive elements 4*q .. 4*q+3 of the tensor numbered cfg.stream
-__host__ __device__ inline void drop_keep4(const DropCfg& cfg, uint32_t q, bool keep[4]) {
+// the two hash words of quad q (elements 4*q .. 4*q+3 of the tensor numbered cfg.stream): element j draws the 16-bit half
+// (j & 1) of word (j >> 1) and is kept when the draw >= thresh >> 16
+__host__ __device__ inline void drop_pair(const DropCfg& cfg, uint32_t q, uint32_t& a, uint32_t& b) {
   // (stream, step, seed) fold into a wave-uniform key; the quad index is the counter
   const uint32_t key = cfg.k0 ^ (cfg.stream * 0x9E3779B1u) ^ (cfg.step * 0x85EBCA77u);
-  const uint32_t a = hash32(q ^ key);
-  const uint32_t b = hash32((a + 0x9E3779B9u) ^ cfg.k1 ^ (q * 0xC2B2AE3Du));
+  a = hash32(q ^ key);
+  b = hash32((a + 0x9E3779B9u) ^ cfg.k1 ^ (q * 0xC2B2AE3Du));
+}
+// keep flags for the 4 consecutive elements 4*q .. 4*q+3 of the tensor numbered cfg.stream
+__host__ __device__ inline void drop_keep4(const DropCfg& cfg, uint32_t q, bool keep[4]) {
+  uint32_t a, b;
+  drop_pair(cfg, q, a, b);
   const uint32_t t16 = cfg.thresh >> 16;
   keep[0] = (a & 0xffffu) >= t16;
   keep[1] = (a >> 16) >= t16;

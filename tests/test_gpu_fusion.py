@@ -370,16 +370,16 @@ def test_lds_windowed_aggregation_against_plain_kernels(n_obj, n_rooms, shuffle,
         assert torch.equal(grads[k], gref[k]), k
     assert net.native().read_state()[1] == 0
     if os.environ.get("HMP_TEST_EXPERIMENTS") == "1":
-        # make EXPERIMENTS=1 builds: the forward window sum on the matrix pipe (agg_fwd_mm_kernel, HMP_AGG_MM=1) is another association of
-        # the same fp32 sums, so stored activations move by a bf16 ulp here and there; this bounds its distance to the edge-ordered form
-        # (also for the shuffled graph, where nearly every edge takes the far-edge path and its overflow walk)
-        monkeypatch.setenv("HMP_AGG_MM", "1")
-        out2, grads2 = fwd_bwd()
+        # make EXPERIMENTS=1 builds: the forward in-window sum by 4x4x4 MFMAs over a count matrix (agg_fwd_w4_kernel, HMP_AGG_W4=1) -- fp32
+        # sums in slot order + far edges: another association (usually the same bits: sums of <= 20 bf16 numbers are mostly exact in
+        # fp32, so no inequality check).  This bounds its distance to the edge-ordered form, also for the shuffled graph (every edge
+        # far: far table, its overflow walk); with the switch on, tests/test_gpu_config5.py compares it against the oracle
+        monkeypatch.setenv("HMP_AGG_W4", "1")
+        out3, grads3 = fwd_bwd()
         assert net.native().read_state()[1] == 0
-        # (no inequality check: sums of <= 20 bf16 numbers are usually EXACT in fp32, whatever the order -- the two forms often agree bit for bit)
-        assert (out2 - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
-        for k in grads2:
-            assert (grads2[k] - gref[k]).norm().item() <= 1e-2 * gref[k].norm().item() + 1e-12, k
+        assert (out3 - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+        for k in grads3:
+            assert (grads3[k] - gref[k]).norm().item() <= 1e-2 * gref[k].norm().item() + 1e-12, k
 
 
 @pytest.mark.parametrize("hidden", [64, 256])

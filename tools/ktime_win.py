@@ -41,12 +41,11 @@ def main():
     assert fn(buf) == 0
     chunks = (n_obj + 63) // 64
     per_block = (chunks + 255) // 256
-    if os.environ.get("HMP_AGG_MM", "1") != "0":  # stamps of agg_fwd_mm_kernel
-        names = {20: "count build + far lists + barrier", 21: "requests (far, root, other, ahead)", 24: "product + barrier",
-                 26: "far sums (+ second round)", 27: "other types, epilogue, stores", 25: "staged registers -> LDS, C cleared",
-                 28: "end barrier", 29: "loop total"}
+    if os.environ.get("HMP_AGG_W4", "0") == "1":  # stamps of agg_fwd_w4_kernel (make EXPERIMENTS=1 KTIME=1)
+        names = {20: "requests ahead + counts + far table + barrier", 24: "product (4x4x4 MFMAs) + barrier", 27: "rows (far / other edges, epilogue, stores)",
+                 25: "staged registers -> LDS, counts cleared", 28: "end barrier", 29: "loop total"}
         for i, nm in names.items():
-            print(f"{nm:36s} {buf[i] / 100.0:10.1f} us   ({buf[i] / 100.0 / per_block:7.2f} us per chunk, {per_block} chunks per workgroup)")
+            print(f"{nm:48s} {buf[i] / 100.0:10.1f} us   ({buf[i] / 100.0 / per_block:7.2f} us per chunk, {per_block} chunks per workgroup)")
         return
     names = {20: "phase A (issue requests)", 21: "phase B+C (rows)", 22: "phase D (regs -> LDS)", 23: "barrier", 24: "loop total"}
     names.update({25: "row: root + bias", 26: "row: .. extents + lane map", 27: "row: .. loads issued", 28: "row: .. loads landed",
