@@ -35,22 +35,32 @@ constexpr int X3_BK = 32;  // K stage
 // wave -- the matrix pipe waits).  A <512 threads, 256 x 256, 4 x 2 waves of 64 x 128> shape (twice the bytes for four times the
 // work) was written against the same template and does not fit the register file: 128 accumulator registers + three pieces of
 // every fragment + the staging registers spill 500-1000 registers at the 256 a wave gets with 8 waves per CU -- not built.
-template <int NT_, int ROWS_, int WMW_, int WNW_>
-struct X3Cfg {
-  static constexpr int NT = NT_, ROWS = ROWS_, WMW = WMW_, WNW = WNW_;
-  static constexpr int MI = ROWS / WMW / 32, NI = ROWS / WNW / 32;  // 32x32 MFMA tiles per wave
-  static constexpr int NV = ROWS * X3_BK / 4 / NT;                  // float4 slots per thread and operand (4)
+// one operand's tile: ROWS rows x X3_BK k, staged by NT threads
+template <int NT_, int ROWS_>
+struct X3Side {
+  static constexpr int NT = NT_, ROWS = ROWS_;
+  static constexpr int NV = ROWS * X3_BK / 4 / NT;  // float4 slots per thread
   static constexpr int PITCH = X3_BK + 8;  // [row][k] image: 40 bf16 = 80 bytes per row (odd multiple of 16 bytes: 8 consecutive rows cover all banks)
   static constexpr int RP = ROWS + 8;      // [k][row] image: bf16 elements per k row
   static constexpr int PLANE = (ROWS * PITCH > X3_BK * RP) ? ROWS * PITCH : X3_BK * RP;
-  static constexpr int LDS_BYTES = 6 * PLANE * 2;
 };
-using X3Small = X3Cfg<256, 128, 2, 2>;
-constexpr int X3_NV = 4;
-static_assert(X3Small::NV == X3_NV, "four float4 slots per thread and operand");
+// RM x RN output tile, WMW x WNW waves; PER_CU workgroups per CU.  <256, 128, 128, 2, 2, 2>: 60 KB of LDS, 64 accumulator registers.
+// <256, 128, 64, 2, 2, 3>: 45 KB, 32 accumulator registers, three workgroups per CU -- for launches whose 128 x 128 tiles would fill the
+// 512 workgroup slots badly (the GAT projections: 516 tiles = one full round + 4 tiles; the GAT input gradients: 172 tiles on 256 CUs)
+template <int NT_, int RM_, int RN_, int WMW_, int WNW_, int PER_CU_>
+struct X3Cfg {
+  static constexpr int NT = NT_, RM = RM_, RN = RN_, WMW = WMW_, WNW = WNW_, PER_CU = PER_CU_;
+  using SA = X3Side<NT_, RM_>;
+  using SB = X3Side<NT_, RN_>;
+  static constexpr int MI = RM / WMW / 32, NI = RN / WNW / 32;  // 32x32 MFMA tiles per wave
+  static constexpr int LDS_BYTES = 3 * (SA::PLANE + SB::PLANE) * 2;
+};
+using X3Small = X3Cfg<256, 128, 128, 2, 2, 2>;
+using X3Narrow = X3Cfg<256, 128, 64, 2, 2, 3>;
 
+template <int NV>
 struct Regs {
-  float4 v[X3_NV];
+  float4 v[NV];
 };
 
 // A (128 x 32) stage of one operand in registers: slot q of a k-contiguous operand ([row][k] in memory) covers row q / 8, k = 4 (q % 8)
@@ -60,10 +70,10 @@ struct Regs {
 // outside the operand when the stage is consumed, one iteration later (a select right here would make the compiler wait for each load
 // before the MFMAs it is meant to overlap with: gemm.hip).
 template <class C, int VEC>
-__device__ __forceinline__ void x3_load(Regs& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int k0, int kend) {
+__device__ __forceinline__ void x3_load(Regs<C::NV>& t, const float* __restrict__ p, int ld, int kcontig, int r0, int R, int k0, int kend) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < X3_NV; ++i) {
+  for (int i = 0; i < C::NV; ++i) {
     const int q = tid + i * C::NT;
     const float* src;
     int o1 = 1, o2 = 2, o3 = 3;
@@ -101,10 +111,10 @@ __device__ __forceinline__ void x3_load(Regs& t, const float* __restrict__ p, in
 }
 
 template <class C>
-__device__ __forceinline__ void x3_mask(Regs& t, int kcontig, int r0, int R, int k0, int kend) {
+__device__ __forceinline__ void x3_mask(Regs<C::NV>& t, int kcontig, int r0, int R, int k0, int kend) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < X3_NV; ++i) {
+  for (int i = 0; i < C::NV; ++i) {
     const int q = tid + i * C::NT;
     if (kcontig) {
       const int r = q / (X3_BK / 4), k4 = (q % (X3_BK / 4)) * 4;
@@ -123,10 +133,10 @@ __device__ __forceinline__ void x3_mask(Regs& t, int kcontig, int r0, int R, int
 
 // the exact three-way split of four consecutive elements -> one 8-byte write per plane
 template <class C>
-__device__ __forceinline__ void x3_store(const Regs& t, __bf16* __restrict__ s, int kcontig) {
+__device__ __forceinline__ void x3_store(const Regs<C::NV>& t, __bf16* __restrict__ s, int kcontig) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < X3_NV; ++i) {
+  for (int i = 0; i < C::NV; ++i) {
     const int q = tid + i * C::NT;
     const float x[4] = {t.v[i].x, t.v[i].y, t.v[i].z, t.v[i].w};
     bf16x4 p1, p2, p3;
@@ -189,16 +199,19 @@ __device__ __forceinline__ void x3_loop(const GemmProblem& P, int a_kc, int b_kc
   // DEPTH register sets, loads DEPTH stages ahead (2 where the registers allow it: a stage is ~1 500 cycles of MFMAs, shorter than a
   // trip to HBM under load; the ones-column forms and the big tile hold more accumulator tiles and keep one set)
   constexpr int DEPTH = (ONES || MI * NI > 4) ? 1 : 2;
-  Regs ra0, rb0, ra1, rb1;
-  auto load = [&](Regs& ra, Regs& rb, int k0) {
-    x3_load<C, AV>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
-    x3_load<C, BV>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
+  using SA = typename C::SA;
+  using SB = typename C::SB;
+  Regs<SA::NV> ra0, ra1;
+  Regs<SB::NV> rb0, rb1;
+  auto load = [&](Regs<SA::NV>& ra, Regs<SB::NV>& rb, int k0) {
+    x3_load<SA, AV>(ra, P.A, P.lda, a_kc, m0, P.M, k0, kend);
+    x3_load<SB, BV>(rb, P.B, P.ldb, b_kc, n0, P.n_real, k0, kend);
   };
-  auto stage = [&](Regs& ra, Regs& rb, int kt) {
-    x3_mask<C>(ra, a_kc, m0, P.M, kt, kend);
-    x3_mask<C>(rb, b_kc, n0, P.n_real, kt, kend);
-    x3_store<C>(ra, As, a_kc);
-    x3_store<C>(rb, Bs, b_kc);
+  auto stage = [&](Regs<SA::NV>& ra, Regs<SB::NV>& rb, int kt) {
+    x3_mask<SA>(ra, a_kc, m0, P.M, kt, kend);
+    x3_mask<SB>(rb, b_kc, n0, P.n_real, kt, kend);
+    x3_store<SA>(ra, As, a_kc);
+    x3_store<SB>(rb, Bs, b_kc);
     __syncthreads();
     if (kt + DEPTH * X3_BK < kend) load(ra, rb, kt + DEPTH * X3_BK);  // this set's next turn
 #pragma unroll
@@ -208,12 +221,12 @@ __device__ __forceinline__ void x3_loop(const GemmProblem& P, int a_kc, int b_kc
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) av[p][i] = x3_fetch<C>(As + p * C::PLANE, a_kc, wm * (MI * 32) + i * 32, ks, lane);
+        for (int i = 0; i < MI; ++i) av[p][i] = x3_fetch<SA>(As + p * SA::PLANE, a_kc, wm * (MI * 32) + i * 32, ks, lane);
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         bf16x8 bv[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bv[p] = x3_fetch<C>(Bs + p * C::PLANE, b_kc, wn * (NI * 32) + j * 32, ks, lane);
+        for (int p = 0; p < 3; ++p) bv[p] = x3_fetch<SB>(Bs + p * SB::PLANE, b_kc, wn * (NI * 32) + j * 32, ks, lane);
         // smallest terms first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -246,11 +259,11 @@ __device__ __forceinline__ void x3_loop(const GemmProblem& P, int a_kc, int b_kc
 
 // FORM: 0 NT, 1 NN, 2 TN, 3 per problem at run time (mixed launches)
 template <class C, bool ONES, int FORM>
-__global__ __launch_bounds__(C::NT, C::NT == 256 ? 2 : 1) void gemm_x3_kernel(const GemmBatch gb) {
+__global__ __launch_bounds__(C::NT, C::PER_CU) void gemm_x3_kernel(const GemmBatch gb) {
   constexpr int MI = C::MI, NI = C::NI;
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
   __bf16* As = reinterpret_cast<__bf16*>(x3_lds);
-  __bf16* Bs = As + 3 * C::PLANE;
+  __bf16* Bs = As + 3 * C::SA::PLANE;
   int pi = 0;
   while (pi + 1 < gb.n && (int)blockIdx.x >= gb.p[pi + 1].tile_start) ++pi;
   const GemmProblem& P = gb.p[pi];
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(C::NT, C::NT == 256 ? 2 : 1) void gemm_x3_kernel(co
   const int z = local % P.ksplit, t = local / P.ksplit;
   const int grp = t / (8 * P.tiles_n), within = t % (8 * P.tiles_n);
   const int rows_in_grp = min(8, P.tiles_m - grp * 8);
-  const int m0 = (grp * 8 + within % rows_in_grp) * C::ROWS, n0 = (within / rows_in_grp) * C::ROWS;
+  const int m0 = (grp * 8 + within % rows_in_grp) * C::RM, n0 = (within / rows_in_grp) * C::RN;
   const int kbeg = z * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
   const int a_kc = FORM == 3 ? (P.trans_a ? 0 : 1) : (FORM == 2 ? 0 : 1);
@@ -270,8 +283,8 @@ __global__ __launch_bounds__(C::NT, C::NT == 256 ? 2 : 1) void gemm_x3_kernel(co
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     return ((ld & 3) == 0 && (a & 15) == 0) ? 4 : (((ld & 1) == 0 && (a & 7) == 0) ? 2 : 1);
   };
-  const int a_vec = (a_kc || m0 + C::ROWS <= P.M) ? vec_of(P.A, P.lda) : 1;
-  const int b_vec = (b_kc || n0 + C::ROWS <= P.n_real) ? vec_of(P.B, P.ldb) : 1;
+  const int a_vec = (a_kc || m0 + C::RM <= P.M) ? vec_of(P.A, P.lda) : 1;
+  const int b_vec = (b_kc || n0 + C::RN <= P.n_real) ? vec_of(P.B, P.ldb) : 1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w % C::WMW, wn = w / C::WMW;
   const bool ones_here = ONES && P.aug_ones && n0 == 0 && wn == 0;  // wave-uniform
@@ -367,13 +380,13 @@ int x3_launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st)
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
     any_ones = any_ones || p.aug_ones != 0;
-    all_tiles += cdiv(p.M, C::ROWS) * cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::ROWS);
+    all_tiles += cdiv(p.M, C::RM) * cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::RN);
   }
-  const int target = C::NT == 256 ? 1024 : 512;  // workgroups over the whole launch when split-K supplies them
+  const int target = 512 * C::PER_CU;  // workgroups over the whole launch when split-K supplies them
   for (int i = 0; i < gb.n; ++i) {
     GemmProblem& p = gb.p[i];
-    p.tiles_m = cdiv(p.M, C::ROWS);
-    p.tiles_n = cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::ROWS);  // the ones column rides in the first column tile
+    p.tiles_m = cdiv(p.M, C::RM);
+    p.tiles_n = cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::RN);  // the ones column rides in the first column tile
     const int tiles = p.tiles_m * p.tiles_n;
     int ks = 1;
     if (want_split && tiles > 0) {  // every slab gets at least one K stage
@@ -450,6 +463,23 @@ int gemm_x3_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st
   for (int i = 0; i < gb.n; ++i) {
     const GemmProblem& p = gb.p[i];
     HMP_CHECK_ARG(!p.aug_ones || (p.trans_a && !p.trans_b && p.N == p.n_real + 1), "gemm_x3: the ones column belongs to the TN form with N = n_real + 1");
+  }
+  // 128 x 64 tiles at three workgroups per CU where the square tile wastes the chip: (a) fewer square tiles than workgroup slots
+  // (the GAT input gradients: 172 tiles on 512 slots -- 0.338 -> 0.324 ms), (b) output widths that fill the last square column
+  // tile badly (N = 192 at batch 2048: 256 padded columns against 192 -- projections 0.307 -> 0.268 ms, input gradients 0.52 -> 0.48).
+  // Not where neither holds: the narrow tile re-reads the row operand once per 64 instead of 128 columns, and these products are
+  // bound by operand traffic (GAT projections, N = 1536: 0.116 ms square, 0.130 ms narrow)
+  if (!want_split) {
+    int64_t t_sq = 0;
+    double pad_sq = 0.0, pad_nr = 0.0;
+    for (int i = 0; i < gb.n; ++i) {
+      t_sq += (int64_t)cdiv(gb.p[i].M, 128) * cdiv(gb.p[i].N, 128);
+      pad_sq += (double)gb.p[i].M * (cdiv(gb.p[i].N, 128) * 128);
+      pad_nr += (double)gb.p[i].M * (cdiv(gb.p[i].N, 64) * 64);
+    }
+    const char* tv = getenv("HMP_GEMM_X3_TILE");  // 128 / 64: pin the square / the narrow tile (tests, measurements)
+    const bool narrow = tv ? (tv[0] == '6') : (t_sq < 410 || pad_nr <= 0.8 * pad_sq);
+    if (narrow) return x3_launch_cfg<X3Narrow>(gb, want_split, max_slabs, st);
   }
   return x3_launch_cfg<X3Small>(gb, want_split, max_slabs, st);
 }

@@ -545,13 +545,15 @@ def test_fp32_gemm_on_the_bf16_pipe_by_three_way_split(ta, tb, M, N, K, lda_pad,
         assert torch.isnan(C[:, N:]).all() and not torch.isnan(C[:, :N]).any()
         return C[:, :N].double()
 
-    monkeypatch.setenv("HMP_GEMM_X3", "2")  # (2: every launch form, also the split-K one the executor keeps on the tall kernel)
-    x3 = run()
     monkeypatch.setenv("HMP_GEMM_X3", "0")
     f32 = run()
-    assert not torch.equal(x3, f32)  # the split kernel really ran
-    scale = (a64.abs().mean() * b64.abs().mean() * K).item()  # ~ sum of |products|
-    e3 = (x3 - ref).abs().max().item()
     e32 = (f32 - ref).abs().max().item()
-    assert e3 <= 2e-6 * scale, (e3, scale)
-    assert e3 <= 2.0 * e32 + 1e-7 * scale, (e3, e32)
+    scale = (a64.abs().mean() * b64.abs().mean() * K).item()  # ~ sum of |products|
+    monkeypatch.setenv("HMP_GEMM_X3", "2")  # (2: every launch form, also the split-K one the executor keeps on the tall kernel)
+    for tile in ("128", "64"):  # the square tile and the 128 x 64 one (three workgroups per CU; chosen when it fills the chip better)
+        monkeypatch.setenv("HMP_GEMM_X3_TILE", tile)
+        x3 = run()
+        assert not torch.equal(x3, f32)  # the split kernel really ran
+        e3 = (x3 - ref).abs().max().item()
+        assert e3 <= 2e-6 * scale, (tile, e3, scale)
+        assert e3 <= 2.0 * e32 + 1e-7 * scale, (tile, e3, e32)
