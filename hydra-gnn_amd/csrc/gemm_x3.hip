@@ -382,7 +382,7 @@ int x3_launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st)
     any_ones = any_ones || p.aug_ones != 0;
     all_tiles += cdiv(p.M, C::RM) * cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::RN);
   }
-  const int target = 512 * C::PER_CU;  // workgroups over the whole launch when split-K supplies them
+  const int target = 512 * C::PER_CU;  // workgroups over the whole launch when split-K supplies them (measured flat from 256 to 2048 at config 3)
   for (int i = 0; i < gb.n; ++i) {
     GemmProblem& p = gb.p[i];
     p.tiles_m = cdiv(p.M, C::RM);
@@ -441,21 +441,33 @@ int x3_launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st)
 
 // Launches of >= 10^9 multiply-adds whose problems are plain fp32 (no bf16-stored operand, no two-piece A, no gather-add term).
 // HMP_GEMM_X3=0: the fp32-MFMA kernels of gemm.hip (tests compare the two).
-bool gemm_x3_takes(const GemmBatch& gb, bool want_split) {
-  // split-K weight gradients stay with the tall / direct fp32 kernels (measured: batch 2048 backward GEMMs 0.52 ms against 0.65 ms
-  // with this kernel's 128 x 128 tiles over a 192 x 307 output; config 3 0.338 against 0.341 ms); HMP_GEMM_X3=2 sends them here too
+// Which launches: plain fp32 problems (no bf16-stored operand, no two-piece A, no gather-add term) of >= 10^9 multiply-adds in total.
+// Split-K weight gradients only over FEWER than 32 768 nodes (GAT at its batch size: 1 548 x 513 outputs over 5 490 nodes -- 0.341 ->
+// 0.280 ms for the step's backward GEMMs against the direct fp32 TN kernel, whose 32 x 32 tiles re-read the operands 10x from HBM);
+// over more nodes the outputs are at most 192 columns wide and the tall fp32 kernel of gemm.hip is faster (0.52 against 0.65 ms at
+// batch 2048).  HMP_GEMM_X3=0: never; =2: every split-K launch.
+static bool x3_takes_problems(const GemmProblem* ps, int n, bool want_split) {
   const char* v = getenv("HMP_GEMM_X3");
   if (v && v[0] == '0') return false;
-  if (want_split && !(v && v[0] == '2')) return false;
-  if (gb.n <= 0) return false;
+  if (n <= 0) return false;
+  const bool all_split = v && v[0] == '2';
   double work = 0.0;
-  for (int i = 0; i < gb.n; ++i) {
-    const GemmProblem& p = gb.p[i];
+  for (int i = 0; i < n; ++i) {
+    const GemmProblem& p = ps[i];
     if (p.a_bf16 || p.b_bf16 || p.c_bf16 || p.h_bf16 || p.a_split || p.g_rowptr) return false;
     if (p.M < 0 || p.N < 0 || p.K < 0) return false;
+    if (want_split && !all_split && p.K >= 32768) return false;
     work += (double)p.M * p.N * p.K;
   }
   return work >= 1e9;
+}
+bool gemm_x3_takes(const GemmBatch& gb, bool want_split) { return x3_takes_problems(gb.p, gb.n, want_split); }
+// the executor's question before it picks the register-direct TN kernel for a step's weight gradients: would one of the launches of
+// these problems (GEMM_MAX_PROB at a time, in order) come here?
+bool gemm_x3_split_takes(const GemmProblem* ps, int n) {
+  for (int base = 0; base < n; base += GEMM_MAX_PROB)
+    if (x3_takes_problems(ps + base, n - base < GEMM_MAX_PROB ? n - base : GEMM_MAX_PROB, true)) return true;
+  return false;
 }
 
 int gemm_x3_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st) {

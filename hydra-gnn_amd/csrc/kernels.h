@@ -62,8 +62,9 @@ int gemm_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
 // same contract on the bf16 matrix pipe (operands rounded to bf16 on their way into LDS, fp32 accumulate): gemm_bf16.hip
 int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
 // fp32 accuracy on the bf16 matrix pipe (three exact bf16 pieces per operand element, six piece products): gemm_x3.hip; takes =
-// every problem of the launch is plain fp32, the launch is big enough and not a split-K one (HMP_GEMM_X3=0: never; =2: split-K launches too)
+// every problem of the launch is plain fp32, the launch is big enough, and split-K launches only over < 32 768 nodes (HMP_GEMM_X3=0: never; =2: every split-K launch)
 bool gemm_x3_takes(const GemmBatch& gb, bool want_split);
+bool gemm_x3_split_takes(const GemmProblem* ps, int n);  // (split-K weight gradients of a step, before the direct TN kernel is chosen)
 int gemm_x3_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st);
 // operand-stationary backward kernels of the 10^6-node regime (gemm_bf16_bwd.hip); *_takes: the problem fits the kernel's limits
 bool gemm_bf16_dx_takes(const GemmProblem& p, bool want_split);

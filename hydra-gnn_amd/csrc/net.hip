@@ -1804,6 +1804,8 @@ int backward_impl(hmp_net* n, const float* d_gout, int ld_gout, float* d_grads, 
     bool direct = n->fuse_now;
     if (direct) {  // register-direct TN kernel (one memory round trip per <= 192-node chunk); all-or-nothing per call
       if (!n->env.tn_direct) direct = false;
+      // weight gradients of >= 10^9 multiply-adds (GAT at its batch size): split-K on the bf16 matrix pipe by the three-way split
+      if (direct && !n->compute_bf16 && !wps.empty() && gemm_x3_split_takes(wps.data(), (int)wps.size())) direct = false;
       for (size_t i = 0; i < wps.size() && direct; ++i)
         if (wps[i].K > TN_DIRECT_SLABS * 384 || wps[i].b_bf16 || wps[i].a_bf16) direct = false;
       for (size_t base = 0; base < wps.size() && direct; base += GEMM_MAX_PROB) {
