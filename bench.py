@@ -624,6 +624,13 @@ def main():
             table[k] = {"kernel": name, "avg_us": round(avg_us, 3), "scopes_per_step": launches // prof_steps,
                         "alg_bytes_per_launch": round(by), "alg_flops_per_launch": round(fl),
                         "GBps": round(by / (avg_us * 1e-6) / 1e9, 2), "TFLOPs": round(fl / (avg_us * 1e-6) / 1e12, 3)}
+        # fp32 GEMM launches of >= 1e9 multiply-adds run on the bf16 matrix pipe by the exact three-way split (csrc/gemm_x3.hip); the
+        # figures stay ALGORITHMIC fp32 flops against the fp32 matrix peak -- the kernel issues six bf16 products per algorithmic one
+        if not (args.precision == "bf16" and args.config == 5) and os.environ.get("HMP_GEMM_X3") != "0":
+            for k in ("gemm_fwd", "gemm_bwd"):
+                if k in table and table[k]["alg_flops_per_launch"] >= 2e9 and not (k == "gemm_bwd" and args.config == 2):
+                    table[k]["kernel"] = ("gemm_x3_kernel (fp32 operands split exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 products "
+                                          "per element product, fp32 accumulate: fp32 accuracy; flops counted once)")
         out["kernel_ms_per_step"] = {n: round(v[0] / prof_steps, 5) for n, v in per.items() if v[1]}
         out["event_overhead_us"] = round(event_overhead_us, 3)
         if table:
