@@ -382,7 +382,9 @@ int x3_launch_cfg(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t st)
     any_ones = any_ones || p.aug_ones != 0;
     all_tiles += cdiv(p.M, C::RM) * cdiv(p.aug_ones ? (p.n_real > 0 ? p.n_real : 1) : p.N, C::RN);
   }
-  const int target = 512 * C::PER_CU;  // workgroups over the whole launch when split-K supplies them (measured flat from 256 to 2048 at config 3)
+  // workgroups over the whole launch when split-K supplies them: one per CU and resident slot -- the kernel time is flat from 256 to 2048
+  // at config 3, and every slab is written here and read again by the gradient un-pack
+  const int target = 256 * C::PER_CU;
   for (int i = 0; i < gb.n; ++i) {
     GemmProblem& p = gb.p[i];
     p.tiles_m = cdiv(p.M, C::RM);
