@@ -780,6 +780,12 @@ int gemm_bf16_launch(GemmBatch& gb, bool want_split, int max_slabs, hipStream_t 
     } else if (p.aug_ones || p.M < 4096 || p.N < 192) big = false;
   }
   if (want_split && !tn_wide) big = false;
+  if (big && !want_split) {  // the 256 x 256 tile runs one workgroup per CU: a launch with fewer tiles than CUs (the 10^4-room products of
+                             // config 5: 40 x 3 tiles) leaves half the chip idle -- 128 x 128 tiles (two per CU) then
+    int64_t t256 = 0;
+    for (int i = 0; i < gb.n; ++i) t256 += (int64_t)cdiv(gb.p[i].M, 256) * cdiv(gb.p[i].N, 256);
+    if (t256 < 256) big = false;
+  }
   const int BT = big ? 256 : 128;
   const int BKB = big ? 32 : 64;
   int start = 0, all_tiles = 0;
