@@ -1537,23 +1537,38 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
             int idv = 0;
             if (wq && base == 0) idv = idw;  // requested one row ago
             else if (lane < cnt) idv = fits ? idc[offq + base + lane] : I.col[b + base + lane];
-            // lane u prepares edge u: BOTH sources are read for every edge, branch-free (the compiler drains the memory counters
-            // at every control-flow join; flat loads into LDS run at a fraction of the ds_read rate): the LDS read aims at the
-            // ring slot or at the all-zero row, the buffer read at the global row or -- through a descriptor of zero records --
-            // at nothing (returns 0 without a memory access); the row is their OR.  Per edge that leaves two readlanes, one
-            // address add and two scalar selects: the scalar unit is shared by the CU's four SIMDs and was the bound (measured:
-            // 615 scalar instructions per row with per-edge scalar address arithmetic).
+            // Round 3: a row's OUT-OF-WINDOW rows (and the rows of an edge type without a window) are requested first, four at a time,
+            // and added last; every batch in between reads LDS only (an out-of-window edge reads the all-zero row there).  Before, an
+            // out-of-window edge sat inside its batch of eight -- LDS read OR buffer read per edge, branch-free -- and the batch waited
+            // for a random 512-byte row from HBM before the next batch was even issued (profiles/r03_n_matrix_pipe_window_sum.md).
+            // fp32 sums: in-window rows in edge order, then the others in edge order -- another association than the plain kernels'.
             const bool inw = lane < cnt && wq && idv >= wlo && idv < whi;
             const int lov = inw ? (idv & (WRING - 1)) * WIN_ROW_BYTES : WRING * WIN_ROW_BYTES;
-            const int gov = (lane < cnt && !inw) ? idv * (ldq * 2) : 0;
-            const unsigned long long mnull = __ballot(inw || lane >= cnt) | (a.dbg ? ~0ull : 0ull);  // edges that read nothing from global memory (dbg: measurement only)
-            auto batch = [&](int u0, auto nb) {
-              constexpr int NB = decltype(nb)::value;
-              uint2 va[NB];
-              // A batch none of whose edges leaves the window (43 % of them at 10 % far neighbours) issues LDS reads only: even a
-              // buffer read through the zero-record descriptor travels the vector-memory pipeline, and the batch waited ~1 us for
-              // its eight of them (measured: 4.2 us per row, ~3 batches; nulling every far read left 89 % of the kernel's time).
-              if (((~mnull >> u0) & ((1ull << NB) - 1ull)) == 0ull) {  // wave-uniform
+            const int gov = idv * (ldq * 2);
+            unsigned long long fm = __ballot(lane < cnt && !inw) & (a.dbg ? 0ull : ~0ull);  // (dbg: measurement only -- no global reads)
+            u32x2 fv[4];
+            auto far_issue = [&]() {  // the next (up to) four set bits of fm
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int u = fm ? __builtin_ctzll(fm) : 0;
+                fv[t] = __builtin_amdgcn_raw_buffer_load_b64(fm ? rs : rs_null, lane * 8, __builtin_amdgcn_readlane(gov, u), 0);
+                fm &= fm - 1ull;  // (0 stays 0)
+              }
+            };
+            auto far_add = [&]() {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                Acc<4> w;
+                widen_bf16x4(w, make_uint2(fv[t][0], fv[t][1]));
+                acc.add(w);
+              }
+            };
+            const bool any_far = fm != 0ull;
+            if (any_far) far_issue();
+            if (wq) {
+              auto batch = [&](int u0, auto nb) {
+                constexpr int NB = decltype(nb)::value;
+                uint2 va[NB];
 #pragma unroll
                 for (int t = 0; t < NB; ++t) va[t] = *reinterpret_cast<const uint2*>(ring + __builtin_amdgcn_readlane(lov, u0 + t) + lane * 8);
 #pragma unroll
@@ -1562,26 +1577,18 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
                   widen_bf16x4(w, va[t]);
                   acc.add(w);
                 }
-                return;
+              };
+              int u0 = 0;
+              for (; cnt - u0 > 2; u0 += 8) batch(u0, std::integral_constant<int, 8>());
+              if (u0 < cnt) batch(u0, std::integral_constant<int, 2>());
+            }
+            if (any_far) {
+              far_add();
+              while (fm) {  // more than four: further rounds, each waited for
+                far_issue();
+                far_add();
               }
-              u32x2 vb[NB];
-#pragma unroll
-              for (int t = 0; t < NB; ++t) {
-                const int u = u0 + t;  // < 64: edges past cnt read the zero row / nothing and add +0
-                const int so = __builtin_amdgcn_readlane(lov, u), sg = __builtin_amdgcn_readlane(gov, u);
-                va[t] = *reinterpret_cast<const uint2*>(ring + so + lane * 8);
-                vb[t] = __builtin_amdgcn_raw_buffer_load_b64(((mnull >> u) & 1ull) ? rs_null : rs, lane * 8, sg, 0);
-              }
-#pragma unroll
-              for (int t = 0; t < NB; ++t) {
-                Acc<4> w;
-                widen_bf16x4(w, make_uint2(va[t].x | vb[t][0], va[t].y | vb[t][1]));
-                acc.add(w);
-              }
-            };
-            int u0 = 0;
-            for (; cnt - u0 > 2; u0 += 8) batch(u0, std::integral_constant<int, 8>());
-            if (u0 < cnt) batch(u0, std::integral_constant<int, 2>());
+            }
           }
           tot.add_div(acc, a.mean ? (float)(e - b) : 1.f);
         }
@@ -2040,50 +2047,69 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_bwd_win_kernel(const WinBwd a
         for (int base = 0; base < e - b; base += 64) {
           const int cnt = min(e - b - base, 64);
           const int idv = lane < cnt ? (fits ? idc[offq + base + lane] : O.t_col[b + base + lane]) : 0;
-          const bool inw = wq && idv >= wlo && idv < whi;
-          // the edge's weight 1 / deg(dst): lane u fetches edge u's (from the ring's table or from global memory)
-          float dv = 1.f;
-          if (a.mean && lane < cnt) {
-            if (dg) dv = inw ? wdeg[idv & (WRING - 1)] : O.degf[idv];
-            else { const int g0 = O.rowptr[idv + 1] - O.rowptr[idv]; dv = 1.f / (float)(g0 > 1 ? g0 : 1); }
+          const bool inw = lane < cnt && wq && idv >= wlo && idv < whi;
+          const bool farl = lane < cnt && !inw;
+          // the edge's weight 1 / deg(dst), lane u = edge u: in-window edges from the ring's table (LDS), the others from global memory --
+          // in TWO registers, so that the LDS batches never wait for the global ones (see agg_fwd_win_kernel: out-of-window rows are
+          // requested first and added last)
+          float dvl = 1.f, dvg = 1.f;
+          if (a.mean) {
+            if (dg) {
+              if (inw) dvl = wdeg[idv & (WRING - 1)];
+              if (farl) dvg = O.degf[idv];
+            } else if (lane < cnt) {
+              const int g0 = O.rowptr[idv + 1] - O.rowptr[idv];
+              dvl = dvg = 1.f / (float)(g0 > 1 ? g0 : 1);
+            }
           }
-          const int dvi = __float_as_int(dv);
-          const bool inl = lane < cnt && inw;
-          const int lov = inl ? (idv & (WRING - 1)) * WIN_ROW_BYTES : WRING * WIN_ROW_BYTES;  // see agg_fwd_win_kernel
-          const int gov = (lane < cnt && !inw) ? idv * (ldq * 2) : 0;
-          const unsigned long long mnull = __ballot(inl || lane >= cnt);
-          auto batch = [&](int u0, auto nb) {
-            constexpr int NB = decltype(nb)::value;
-            uint2 va[NB];
-            if (((~mnull >> u0) & ((1ull << NB) - 1ull)) == 0ull) {  // wave-uniform: no edge of the batch leaves the window (see agg_fwd_win_kernel)
+          const int dvli = __float_as_int(dvl), dvgi = __float_as_int(dvg);
+          const int lov = inw ? (idv & (WRING - 1)) * WIN_ROW_BYTES : WRING * WIN_ROW_BYTES;  // see agg_fwd_win_kernel
+          const int gov = idv * (ldq * 2);
+          unsigned long long fm = __ballot(farl);
+          u32x2 fv[4];
+          int fu[4];
+          auto far_issue = [&]() {  // the next (up to) four set bits of fm
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              fu[t] = fm ? __builtin_ctzll(fm) : 0;
+              fv[t] = __builtin_amdgcn_raw_buffer_load_b64(fm ? rs : rs_null, cc * 2, __builtin_amdgcn_readlane(gov, fu[t]), 0);
+              fm &= fm - 1ull;  // (0 stays 0)
+            }
+          };
+          auto far_add = [&]() {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              Acc<4> w;
+              widen_bf16x4(w, make_uint2(fv[t][0], fv[t][1]));
+              if (a.mean) acc.add_mul(w, __int_as_float(__builtin_amdgcn_readlane(dvgi, fu[t]))); else acc.add(w);  // (a null read: 0 x a finite weight)
+            }
+          };
+          const bool any_far = fm != 0ull;
+          if (any_far) far_issue();
+          if (wq) {
+            auto batch = [&](int u0, auto nb) {
+              constexpr int NB = decltype(nb)::value;
+              uint2 va[NB];
 #pragma unroll
               for (int t = 0; t < NB; ++t) va[t] = *reinterpret_cast<const uint2*>(ring + __builtin_amdgcn_readlane(lov, u0 + t) + lane * 8);
 #pragma unroll
               for (int t = 0; t < NB; ++t) {
                 Acc<4> w;
                 widen_bf16x4(w, va[t]);
-                if (a.mean) acc.add_mul(w, __int_as_float(__builtin_amdgcn_readlane(dvi, u0 + t))); else acc.add(w);
+                if (a.mean) acc.add_mul(w, __int_as_float(__builtin_amdgcn_readlane(dvli, u0 + t))); else acc.add(w);
               }
-              return;
+            };
+            int u0 = 0;
+            for (; cnt - u0 > 2; u0 += 8) batch(u0, std::integral_constant<int, 8>());
+            if (u0 < cnt) batch(u0, std::integral_constant<int, 2>());
+          }
+          if (any_far) {
+            far_add();
+            while (fm) {  // more than four: further rounds, each waited for
+              far_issue();
+              far_add();
             }
-            u32x2 vb[NB];
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-              const int u = u0 + t;
-              const int so = __builtin_amdgcn_readlane(lov, u), sg = __builtin_amdgcn_readlane(gov, u);
-              va[t] = *reinterpret_cast<const uint2*>(ring + so + lane * 8);
-              vb[t] = __builtin_amdgcn_raw_buffer_load_b64(((mnull >> u) & 1ull) ? rs_null : rs, cc * 2, sg, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-              Acc<4> w;
-              widen_bf16x4(w, make_uint2(va[t].x | vb[t][0], va[t].y | vb[t][1]));
-              if (a.mean) acc.add_mul(w, __int_as_float(__builtin_amdgcn_readlane(dvi, u0 + t))); else acc.add(w);
-            }
-          };
-          int u0 = 0;
-          for (; cnt - u0 > 2; u0 += 8) batch(u0, std::integral_constant<int, 8>());
-          if (u0 < cnt) batch(u0, std::integral_constant<int, 2>());
+          }
         }
         if (cin) store_z<DZB>(acc, S.dz, (int64_t)row * S.lddz + O.coff + c0);
       }
