@@ -1221,11 +1221,12 @@ __global__ __launch_bounds__(WIN_THREADS_CHAIN) void chain_kernel(const ChainArg
 // the CU ONCE per launch, with coalesced 16-byte loads issued one chunk ahead (they land while the current chunk computes).
 // The chunk's CSR slice (row extents and neighbour ids of every incoming edge type: one contiguous range per type) is staged
 // in LDS the same way, two / one chunks ahead.  A row then costs LDS reads only, except for the neighbours outside the window
-// (the 10 % global edges; the other edge types, e.g. the room row of an object).  Lane u of the wave computes edge u's source
-// address -- a slot of the LDS ring or a row in global memory -- as ONE generic (flat) pointer, so the row loads of a batch
-// of 8 edges are branch-free flat loads whatever the mix.  Sums run in edge order through one accumulator per edge type,
-// whatever the source of a row: bit-identical to the kernels above.  Only the edge type whose source index space IS the destination's (objects -> objects) is windowed -- for bipartite
-// types every source row is used once and staging buys nothing.
+// (the 10 % global edges; the other edge types, e.g. the room row of an object).  Those are requested FIRST, four rows at a time
+// (buffer loads at a scalar offset; a descriptor of zero records where there is no such edge), the in-window edges follow in
+// batches of eight LDS reads at scalar-computed slots (an out-of-window edge reads the all-zero row there), and the requested rows
+// are added LAST (round 3; rounds 1-2 mixed both kinds inside a batch and waited for HBM per batch).  One accumulator per edge type;
+// in-window rows in edge order, then the others in edge order.  Only the edge type whose source index space IS the destination's
+// (objects -> objects) is windowed -- for bipartite types every source row is used once and staging buys nothing.
 constexpr int WIN_THREADS = 1024;
 constexpr int WIN_WAVES = WIN_THREADS / 64;
 constexpr int WIN_ROW_BYTES = 512;  // 256 bf16
@@ -1451,7 +1452,8 @@ __global__ __launch_bounds__(WIN_THREADS) void agg_fwd_win_kernel(const WinFwd a
       // all of the wave's rows are ONE lane-parallel LDS read per chunk and reach the scalar unit by readlane; (b) the neighbour ids
       // of the NEXT row's window list and of its deferred list are requested while this row computes; (c) the edge type after the
       // window one (rooms -> objects: one or two global rows) has its rows requested BEFORE the window batches and is added after
-      // them -- same accumulators, same order of additions: bit-identical to the plain kernels.
+      // them -- same accumulators, same order of additions (the out-of-window rows of the window list are added behind the in-window
+      // ones since the far-first change below: fp32, mostly the same bits).
       const int WQ = D.win_in, DQ = (fits && WQ + 1 < nq) ? WQ + 1 : -1;  // wave-uniform
       int rpv = 0;  // lane 8 q + 2 g + h: extent h of the wave's g-th row, edge type q
       if (fits && (lane >> 3) < nq) rpv = rp[(lane >> 3) * WRP + ((lane & 7) >> 1) * WIN_WAVES + wave + (lane & 1)];
