@@ -327,10 +327,12 @@ def test_bf16_mode_activation_storage_is_bit_identical(n_obj, n_rooms, monkeypat
 @pytest.mark.parametrize("n_obj,n_rooms,shuffle", [(40000, 400, False), (140000, 1400, False), (40000, 400, True)])
 def test_lds_windowed_aggregation_against_plain_kernels(n_obj, n_rooms, shuffle, monkeypatch):
     """bf16 mode, 256-wide layers, >= 16384 rows: persistent workgroups keep a sliding ring of source rows in LDS and serve
-    in-window neighbours from there (agg_fwd_win_kernel / agg_bwd_win_kernel).  Same sums in the same edge order: logits and
-    every gradient are BIT-identical to the plain one-wave-per-row kernels (HMP_AGG_WIN=0), also when the numbering has no
-    locality at all (object ids shuffled: nearly every neighbour takes the prefetch-slot / direct global path, many more
-    than the slots hold) and in training mode with dropout."""
+    in-window neighbours from there (agg_fwd_win_kernel / agg_bwd_win_kernel); a row's out-of-window rows are requested first and
+    added behind the in-window ones (round 3) -- another association of the same fp32 sum than the plain one-wave-per-row kernels'
+    (HMP_AGG_WIN=0), but sums of <= 20 bf16 numbers of one layer's scale are EXACT in fp32, so logits and every gradient still
+    come out with the same bits on these graphs: also when the numbering has no locality at all (object ids shuffled: nearly every
+    neighbour is out of the window, several rounds of four per row) and in training mode with dropout.  (Should a new graph ever
+    break the equality by a rounding, this comparison has to take a tolerance; the oracle comparison is tests/test_gpu_config5.py.)"""
     monkeypatch.setenv("HMP_BF16_ALL", "1")
     kw = dict(input_dim_dict={"objects": 256, "rooms": 256}, output_dim=26, conv_block="GraphSAGE", hidden_dim=256, num_layers=3, dropout=0.25)
     g = workloads.big_hetero_graph(n_obj=n_obj, n_rooms=n_rooms, seed=13)
